@@ -1,0 +1,662 @@
+// icpx_capi.hip — implementation of include/icpx/icpx.h.
+//
+// Host side of the drop-in boundary: argument checks, device buffers, path selection and kernel
+// launches.  There is no CPU compute path in here: when no gfx950 device is present every entry
+// point fails with ICPX_ERR_NO_DEVICE.
+//
+// Paths
+//   fused   n <= 4096 and the target cloud fits LDS: one workgroup per scan pair runs the whole
+//           converge loop (icpx_pair.h).  Also what icpx_converge_batch launches, one workgroup
+//           per pair.
+//   large   everything else: exact uniform-grid (or tiled brute-force) NN + multi-workgroup
+//           TREE64 reductions + a one-lane Kabsch/termination kernel per iteration, chained on
+//           the stream with a device-side done flag (icpx_large.h).
+
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+#include "icpx_host.h"
+#include "icpx_large.h"
+#include "icpx_nn.h"
+#include "icpx_pair.h"
+
+namespace icpx {
+
+std::string& last_error_ref() {
+    static thread_local std::string s;
+    return s;
+}
+
+namespace {
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+struct DeviceInfo {
+    bool ok = false;
+    double clock_to_s = 1e-8;
+    int cus = 256;
+    std::string arch;
+};
+
+std::mutex g_mu;
+std::unordered_map<int, DeviceInfo> g_devinfo;
+
+int device_info(int device, DeviceInfo** out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_devinfo.find(device);
+    if (it == g_devinfo.end()) {
+        DeviceInfo di;
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess)
+            return fail(ICPX_ERR_NO_DEVICE, "hipGetDeviceProperties(%d) failed: %s", device,
+                        hipGetErrorString(e));
+        di.arch = prop.gcnArchName;
+        if (di.arch.rfind("gfx950", 0) != 0)
+            return fail(ICPX_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                        device, di.arch.c_str());
+        int khz = 0;
+        e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device);
+        if (e != hipSuccess || khz <= 0) khz = 100000;
+        di.clock_to_s = 1.0 / (static_cast<double>(khz) * 1e3);
+        di.cus = prop.multiProcessorCount;
+        di.ok = true;
+        it = g_devinfo.emplace(device, di).first;
+    }
+    *out = &it->second;
+    return ICPX_OK;
+}
+
+int resolve_device(int requested, int* device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(ICPX_ERR_NO_DEVICE, "no HIP device visible (%s); icpx has no CPU path",
+                    e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    }
+    if (requested < 0) {
+        ICPX_HIP(hipGetDevice(device));
+    } else {
+        if (requested >= count) return fail(ICPX_ERR_INVALID, "device %d out of range (%d visible)", requested, count);
+        *device = requested;
+    }
+    return ICPX_OK;
+}
+
+int next_pow2(int v) {
+    int p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct PairGeom {
+    int qpt, threads, tcap, scap;
+    size_t lds;
+};
+
+// does a pair of this size fit the fused kernel?
+bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g) {
+    if (n > kPairMaxN || m > (1 << 20)) return false;
+    PairGeom r;
+    if (n <= 256) { r.qpt = 1; r.threads = 256; }
+    else if (n <= 512) { r.qpt = 2; r.threads = 256; }
+    else if (n <= 1024) { r.qpt = 2; r.threads = 512; }
+    else if (n <= 2048) { r.qpt = 4; r.threads = 512; }
+    else { r.qpt = 8; r.threads = 512; }
+    r.tcap = static_cast<int>((m + 1) & ~int64_t(1));
+    if (r.tcap < 2) r.tcap = 2;
+    r.scap = (dim == 2 && method == ICPX_TRIMMED) ? next_pow2(static_cast<int>(n)) : 0;
+    r.lds = pair_lds_bytes(dim, r.tcap, r.scap);
+    if (r.lds > kMaxLds) return false;
+    if (g) *g = r;
+    return true;
+}
+
+template <int D, int METHOD, int QPT, int TMAX>
+int launch_one(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
+    auto kern = pair_kernel<D, METHOD, QPT, TMAX>;
+    static std::mutex mu;
+    static std::unordered_map<int, bool> attr_set;  // per device
+    int dev = 0;
+    ICPX_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!attr_set[dev]) {
+            ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(kMaxLds)));
+            attr_set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_pairs)), dim3(g.threads), g.lds, stream, pb);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+template <int D, int METHOD>
+int launch_dm(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
+    if (g.qpt == 1) return launch_one<D, METHOD, 1, 256>(pb, n_pairs, g, stream);
+    if (g.qpt == 2 && g.threads == 256) return launch_one<D, METHOD, 2, 256>(pb, n_pairs, g, stream);
+    if (g.qpt == 2) return launch_one<D, METHOD, 2, 512>(pb, n_pairs, g, stream);
+    if (g.qpt == 4) return launch_one<D, METHOD, 4, 512>(pb, n_pairs, g, stream);
+    return launch_one<D, METHOD, 8, 512>(pb, n_pairs, g, stream);
+}
+
+int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
+    if (n_pairs <= 0) return ICPX_OK;
+    pb.lds_target_cap = g.tcap;
+    pb.lds_sort_cap = g.scap;
+    if (pb.dim == 2) {
+        if (pb.method == ICPX_VANILLA) return launch_dm<2, ICPX_VANILLA>(pb, n_pairs, g, stream);
+        return launch_dm<2, ICPX_TRIMMED>(pb, n_pairs, g, stream);
+    }
+    if (pb.method == ICPX_VANILLA) return launch_dm<3, ICPX_VANILLA>(pb, n_pairs, g, stream);
+    return launch_dm<3, ICPX_TRIMMED>(pb, n_pairs, g, stream);
+}
+
+icpx_criteria no_criteria() {
+    icpx_criteria c;
+    std::memset(&c, 0, sizeof(c));
+    return c;
+}
+
+// per-device grow-only workspace for the handle-free entry points
+struct Workspace {
+    std::mutex mu;
+    DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2;
+};
+Workspace& workspace(int device) {
+    static std::mutex mu;
+    static std::unordered_map<int, Workspace*> ws;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = ws.find(device);
+    if (it == ws.end()) it = ws.emplace(device, new Workspace()).first;
+    return *it->second;
+}
+
+}  // namespace
+}  // namespace icpx
+
+using namespace icpx;
+
+struct icpx_ctx {
+    int dim = 0, method = 0;
+    icpx_params prm{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0, m = 0;
+    bool begun = false;
+    bool large = false;
+    PairGeom geom{};
+    DevBuf src, dst, cur, off, guess, m_point, m_pair, m_cost, pair_tmp, state, out;
+    LargeIcp* lg = nullptr;
+};
+
+namespace {
+
+int check_handle(icpx_handle h) {
+    if (!h) return fail(ICPX_ERR_INVALID, "null handle");
+    return ICPX_OK;
+}
+
+int upload_pair(icpx_ctx* h, const double* source, int64_t n, const double* target, int64_t m,
+                const double* guess) {
+    const int D = h->dim, XN = (D + 1) * (D + 1);
+    ICPX_TRY(h->src.reserve(sizeof(double) * D * (n > 0 ? n : 1)));
+    ICPX_TRY(h->dst.reserve(sizeof(double) * D * (m > 0 ? m : 1)));
+    ICPX_TRY(h->cur.reserve(sizeof(double) * D * (n > 0 ? n : 1)));
+    ICPX_TRY(h->off.reserve(sizeof(int64_t) * 4));
+    ICPX_TRY(h->guess.reserve(sizeof(double) * 16));
+    ICPX_TRY(h->m_point.reserve(sizeof(int64_t) * (n > 0 ? n : 1)));
+    ICPX_TRY(h->m_pair.reserve(sizeof(int64_t) * (n > 0 ? n : 1)));
+    ICPX_TRY(h->m_cost.reserve(sizeof(double) * (n > 0 ? n : 1)));
+    ICPX_TRY(h->pair_tmp.reserve(sizeof(int32_t) * (n > 0 ? n : 1)));
+    ICPX_TRY(h->state.reserve(sizeof(PairState)));
+    ICPX_TRY(h->out.reserve(sizeof(icpx_state)));
+    if (n > 0) ICPX_HIP(hipMemcpyAsync(h->src.p, source, sizeof(double) * D * n, hipMemcpyDefault, h->stream));
+    if (m > 0) ICPX_HIP(hipMemcpyAsync(h->dst.p, target, sizeof(double) * D * m, hipMemcpyDefault, h->stream));
+    int64_t off[4] = {0, n, 0, m};
+    ICPX_HIP(hipMemcpyAsync(h->off.p, off, sizeof(off), hipMemcpyHostToDevice, h->stream));
+    ICPX_HIP(hipMemcpyAsync(h->guess.p, guess, sizeof(double) * XN, hipMemcpyDefault, h->stream));
+    // the pageable host staging above must be consumed before `off` goes out of scope
+    ICPX_HIP(hipStreamSynchronize(h->stream));
+    h->n = n;
+    h->m = m;
+    return ICPX_OK;
+}
+
+void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
+    std::memset(&pb, 0, sizeof(pb));
+    pb.dim = h->dim;
+    pb.method = h->method;
+    pb.src = h->src.as<double>();
+    pb.src_off = h->off.as<int64_t>();
+    pb.dst = h->dst.as<double>();
+    pb.dst_off = h->off.as<int64_t>() + 2;
+    pb.guesses = h->guess.as<double>();
+    pb.cur = h->cur.as<double>();
+    pb.m_point = h->m_point.as<int64_t>();
+    pb.m_pair = h->m_pair.as<int64_t>();
+    pb.m_cost = h->m_cost.as<double>();
+    pb.pair_tmp = h->pair_tmp.as<int32_t>();
+    pb.states = h->state.as<PairState>();
+    pb.out_states = h->out.as<icpx_state>();
+    pb.crit = no_criteria();
+    pb.overlap_rate = h->prm.overlap_rate;
+    pb.max_distance = h->prm.max_distance;
+    pb.clock_to_s = di.clock_to_s;
+}
+
+int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* target, int64_t m,
+                 const double* guess) {
+    if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "negative cloud size");
+    if ((n > 0 && !source) || (m > 0 && !target) || !guess)
+        return fail(ICPX_ERR_INVALID, "null source/target/guess");
+    if (n > INT32_MAX / 4 || m > INT32_MAX / 4) return fail(ICPX_ERR_UNSUPPORTED, "cloud too large");
+    h->begun = false;
+    bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom);
+    // the tiled brute force of the large path is only chosen explicitly
+    h->large = !fused;
+    if (h->large && (n == 0 || m == 0)) {
+        // empty clouds carry no work: run them through the fused kernel's no-op path
+        h->large = !fused_fits(h->dim, h->method, n, m, &h->geom);
+    }
+    return ICPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icpx_version(void) { return ICPX_VERSION; }
+
+const char* icpx_last_error(void) { return last_error_ref().c_str(); }
+
+void icpx_default_params(icpx_params* p) {
+    if (!p) return;
+    p->overlap_rate = 0.9;  // trimmed.cpp:28
+    p->max_distance = 1.0;  // trimmed_3d.cpp:27
+    p->nn_mode = ICPX_NN_AUTO;
+    p->device = -1;
+    p->stream = nullptr;
+}
+
+int icpx_init(int device) {
+    int dev = 0;
+    ICPX_TRY(resolve_device(device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    ICPX_HIP(hipFree(nullptr));
+    return ICPX_OK;
+}
+
+int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out) {
+    if (!out) return fail(ICPX_ERR_INVALID, "null out handle");
+    *out = nullptr;
+    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (method != ICPX_VANILLA && method != ICPX_TRIMMED)
+        return fail(ICPX_ERR_INVALID, "unknown method %d", method);
+    icpx_params prm;
+    icpx_default_params(&prm);
+    if (params) prm = *params;
+    if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_GRID)
+        return fail(ICPX_ERR_INVALID, "unknown nn_mode %d", prm.nn_mode);
+    int dev = 0;
+    ICPX_TRY(resolve_device(prm.device, &dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    icpx_ctx* h = new (std::nothrow) icpx_ctx();
+    if (!h) return fail(ICPX_ERR_NOMEM, "out of host memory");
+    h->dim = dim;
+    h->method = method;
+    h->prm = prm;
+    h->device = dev;
+    h->stream = static_cast<hipStream_t>(prm.stream);
+    *out = h;
+    return ICPX_OK;
+}
+
+int icpx_destroy(icpx_handle h) {
+    if (!h) return ICPX_OK;
+    DeviceGuard g;
+    (void)g.enter(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (DevBuf* b : {&h->src, &h->dst, &h->cur, &h->off, &h->guess, &h->m_point, &h->m_pair,
+                      &h->m_cost, &h->pair_tmp, &h->state, &h->out})
+        b->release();
+    if (h->lg) large_destroy(h->lg);
+    delete h;
+    return ICPX_OK;
+}
+
+int icpx_begin(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
+               const double* guess) {
+    ICPX_TRY(check_handle(h));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(h->device, &di));
+    ICPX_TRY(begin_common(h, source, n, target, m, guess));
+    if (h->large) {
+        if (!h->lg) ICPX_TRY(large_create(h->dim, h->method, h->prm, di->clock_to_s, h->stream, &h->lg));
+        ICPX_TRY(large_begin(h->lg, source, n, target, m, guess));
+        h->n = n;
+        h->m = m;
+    } else {
+        ICPX_TRY(upload_pair(h, source, n, target, m, guess));
+        PairBatch pb;
+        fill_batch(h, pb, *di);
+        pb.do_setup = 1;
+        pb.check = 0;
+        pb.max_steps = 0;
+        ICPX_TRY(launch_pairs(pb, 1, h->geom, h->stream));
+    }
+    h->begun = true;
+    return ICPX_OK;
+}
+
+int icpx_iterate(icpx_handle h) {
+    ICPX_TRY(check_handle(h));
+    if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_iterate before icpx_begin");
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(h->device, &di));
+    if (h->large) return large_iterate(h->lg);
+    PairBatch pb;
+    fill_batch(h, pb, *di);
+    pb.do_setup = 0;
+    pb.check = 0;
+    pb.max_steps = 1;
+    return launch_pairs(pb, 1, h->geom, h->stream);
+}
+
+int icpx_converge(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
+                  const double* guess, const icpx_criteria* criteria, icpx_state* out) {
+    auto t0 = std::chrono::steady_clock::now();  // driver.h:53
+    ICPX_TRY(check_handle(h));
+    if (!criteria || !out) return fail(ICPX_ERR_INVALID, "null criteria/out");
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(h->device, &di));
+    ICPX_TRY(begin_common(h, source, n, target, m, guess));
+    if (h->large) {
+        if (!h->lg) ICPX_TRY(large_create(h->dim, h->method, h->prm, di->clock_to_s, h->stream, &h->lg));
+        ICPX_TRY(large_begin(h->lg, source, n, target, m, guess));
+        h->n = n;
+        h->m = m;
+        h->begun = true;
+        return large_converge(h->lg, criteria, t0, out);
+    }
+    ICPX_TRY(upload_pair(h, source, n, target, m, guess));
+    PairBatch pb;
+    fill_batch(h, pb, *di);
+    pb.crit = *criteria;
+    pb.do_setup = 1;
+    pb.check = 1;
+    pb.max_steps = UINT64_MAX;
+    pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ICPX_TRY(launch_pairs(pb, 1, h->geom, h->stream));
+    ICPX_HIP(hipMemcpyAsync(out, h->out.p, sizeof(icpx_state), hipMemcpyDefault, h->stream));
+    ICPX_HIP(hipStreamSynchronize(h->stream));
+    h->begun = true;
+    return ICPX_OK;
+}
+
+int icpx_cost(icpx_handle h, double* out) {
+    ICPX_TRY(check_handle(h));
+    if (!out) return fail(ICPX_ERR_INVALID, "null out");
+    if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_cost before icpx_begin");
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    if (h->large) return large_cost(h->lg, out);
+    ICPX_HIP(hipMemcpyAsync(out, &h->state.as<PairState>()->cost, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    ICPX_HIP(hipStreamSynchronize(h->stream));
+    return ICPX_OK;
+}
+
+int icpx_transform(icpx_handle h, double* out) {
+    ICPX_TRY(check_handle(h));
+    if (!out) return fail(ICPX_ERR_INVALID, "null out");
+    if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_transform before icpx_begin");
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    const int XN = (h->dim + 1) * (h->dim + 1);
+    if (h->large) return large_transform(h->lg, out);
+    ICPX_HIP(hipMemcpyAsync(out, h->state.as<PairState>()->transform, sizeof(double) * XN, hipMemcpyDeviceToHost, h->stream));
+    ICPX_HIP(hipStreamSynchronize(h->stream));
+    return ICPX_OK;
+}
+
+int icpx_sizes(icpx_handle h, int64_t* n, int64_t* m) {
+    ICPX_TRY(check_handle(h));
+    if (n) *n = h->n;
+    if (m) *m = h->m;
+    return ICPX_OK;
+}
+
+int icpx_matches(icpx_handle h, int64_t* point, int64_t* pair, double* cost) {
+    ICPX_TRY(check_handle(h));
+    if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_matches before icpx_begin");
+    const int64_t n = h->n;
+    if (n == 0) return ICPX_OK;
+    if (h->dim == 3) {
+        // Vanilla3d / Trimmed3d never touch `matches` (icp.h:129 value-initialises them)
+        if (point) std::memset(point, 0, sizeof(int64_t) * n);
+        if (pair) std::memset(pair, 0, sizeof(int64_t) * n);
+        if (cost) std::memset(cost, 0, sizeof(double) * n);
+        return ICPX_OK;
+    }
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    if (h->large) return large_matches(h->lg, point, pair, cost);
+    if (point) ICPX_HIP(hipMemcpyAsync(point, h->m_point.p, sizeof(int64_t) * n, hipMemcpyDefault, h->stream));
+    if (pair) ICPX_HIP(hipMemcpyAsync(pair, h->m_pair.p, sizeof(int64_t) * n, hipMemcpyDefault, h->stream));
+    if (cost) ICPX_HIP(hipMemcpyAsync(cost, h->m_cost.p, sizeof(double) * n, hipMemcpyDefault, h->stream));
+    ICPX_HIP(hipStreamSynchronize(h->stream));
+    return ICPX_OK;
+}
+
+int icpx_debug_neighbors(icpx_handle h, int64_t* indices, double* distances) {
+    ICPX_TRY(check_handle(h));
+    if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_debug_neighbors before icpx_begin");
+    if (h->dim != 3) return fail(ICPX_ERR_INVALID, "neighbors exist for the 3D methods only");
+    const int64_t n = h->n;
+    if (n == 0) return ICPX_OK;
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    if (h->large) return large_neighbors(h->lg, indices, distances);
+    if (indices) ICPX_HIP(hipMemcpyAsync(indices, h->m_pair.p, sizeof(int64_t) * n, hipMemcpyDefault, h->stream));
+    if (distances) ICPX_HIP(hipMemcpyAsync(distances, h->m_cost.p, sizeof(double) * n, hipMemcpyDefault, h->stream));
+    ICPX_HIP(hipStreamSynchronize(h->stream));
+    return ICPX_OK;
+}
+
+int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t n_pairs,
+                        const double* source, const int64_t* source_offsets,
+                        const double* target, const int64_t* target_offsets,
+                        const double* guesses, const icpx_criteria* criteria,
+                        icpx_state* out_states) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (method != ICPX_VANILLA && method != ICPX_TRIMMED) return fail(ICPX_ERR_INVALID, "unknown method %d", method);
+    if (n_pairs < 0) return fail(ICPX_ERR_INVALID, "negative n_pairs");
+    if (n_pairs == 0) return ICPX_OK;
+    if (!source_offsets || !target_offsets || !criteria || !out_states)
+        return fail(ICPX_ERR_INVALID, "null offsets/criteria/out_states");
+    if (n_pairs > (1 << 30)) return fail(ICPX_ERR_UNSUPPORTED, "too many pairs");
+    icpx_params prm;
+    icpx_default_params(&prm);
+    if (params) prm = *params;
+    int dev = 0;
+    ICPX_TRY(resolve_device(prm.device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    hipStream_t stream = static_cast<hipStream_t>(prm.stream);
+
+    int64_t n_max = 0, m_max = 0;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        int64_t n = source_offsets[p + 1] - source_offsets[p];
+        int64_t m = target_offsets[p + 1] - target_offsets[p];
+        if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "offsets must be non-decreasing (pair %lld)", (long long)p);
+        if (n > n_max) n_max = n;
+        if (m > m_max) m_max = m;
+    }
+    const int64_t n_total = source_offsets[n_pairs], m_total = target_offsets[n_pairs];
+    if ((n_total > 0 && !source) || (m_total > 0 && !target)) return fail(ICPX_ERR_INVALID, "null source/target");
+    PairGeom geom;
+    if (!fused_fits(dim, method, n_max, m_max, &geom))
+        return fail(ICPX_ERR_UNSUPPORTED,
+                    "icpx_converge_batch: largest pair (%lld x %lld points) exceeds the fused kernel's limits; "
+                    "run such pairs through icpx_converge", (long long)n_max, (long long)m_max);
+
+    Workspace& ws = workspace(dev);
+    std::lock_guard<std::mutex> lk(ws.mu);
+    const int XN = (dim + 1) * (dim + 1);
+    const double* d_src = source;
+    const double* d_dst = target;
+    const double* d_guess = guesses;
+    if (n_total > 0 && !is_device_ptr(source)) {
+        ICPX_TRY(ws.src.reserve(sizeof(double) * dim * n_total));
+        ICPX_HIP(hipMemcpyAsync(ws.src.p, source, sizeof(double) * dim * n_total, hipMemcpyHostToDevice, stream));
+        d_src = ws.src.as<double>();
+    }
+    if (m_total > 0 && !is_device_ptr(target)) {
+        ICPX_TRY(ws.dst.reserve(sizeof(double) * dim * m_total));
+        ICPX_HIP(hipMemcpyAsync(ws.dst.p, target, sizeof(double) * dim * m_total, hipMemcpyHostToDevice, stream));
+        d_dst = ws.dst.as<double>();
+    }
+    if (guesses && !is_device_ptr(guesses)) {
+        ICPX_TRY(ws.guesses.reserve(sizeof(double) * XN * n_pairs));
+        ICPX_HIP(hipMemcpyAsync(ws.guesses.p, guesses, sizeof(double) * XN * n_pairs, hipMemcpyHostToDevice, stream));
+        d_guess = ws.guesses.as<double>();
+    }
+    ICPX_TRY(ws.soff.reserve(sizeof(int64_t) * (n_pairs + 1)));
+    ICPX_TRY(ws.doff.reserve(sizeof(int64_t) * (n_pairs + 1)));
+    ICPX_HIP(hipMemcpyAsync(ws.soff.p, source_offsets, sizeof(int64_t) * (n_pairs + 1), hipMemcpyHostToDevice, stream));
+    ICPX_HIP(hipMemcpyAsync(ws.doff.p, target_offsets, sizeof(int64_t) * (n_pairs + 1), hipMemcpyHostToDevice, stream));
+    ICPX_TRY(ws.states.reserve(sizeof(PairState) * n_pairs));
+    const bool out_on_device = is_device_ptr(out_states);
+    icpx_state* d_out = out_states;
+    if (!out_on_device) {
+        ICPX_TRY(ws.out.reserve(sizeof(icpx_state) * n_pairs));
+        d_out = ws.out.as<icpx_state>();
+    }
+
+    PairBatch pb;
+    std::memset(&pb, 0, sizeof(pb));
+    pb.dim = dim;
+    pb.method = method;
+    pb.src = d_src;
+    pb.src_off = ws.soff.as<int64_t>();
+    pb.dst = d_dst;
+    pb.dst_off = ws.doff.as<int64_t>();
+    pb.guesses = d_guess;
+    pb.states = ws.states.as<PairState>();
+    pb.out_states = d_out;
+    pb.crit = *criteria;
+    pb.overlap_rate = prm.overlap_rate;
+    pb.max_distance = prm.max_distance;
+    pb.clock_to_s = di->clock_to_s;
+    pb.do_setup = 1;
+    pb.check = 1;
+    pb.max_steps = UINT64_MAX;
+    pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ICPX_TRY(launch_pairs(pb, n_pairs, geom, stream));
+    if (!out_on_device) {
+        ICPX_HIP(hipMemcpyAsync(out_states, d_out, sizeof(icpx_state) * n_pairs, hipMemcpyDeviceToHost, stream));
+    }
+    // the offset arrays are the caller's host memory: finish the copies before returning
+    ICPX_HIP(hipStreamSynchronize(stream));
+    return ICPX_OK;
+}
+
+int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+            int64_t* idx, double* d2, int mode, int device, void* stream_) {
+    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "negative cloud size");
+    if (mode < ICPX_NN_AUTO || mode > ICPX_NN_GRID) return fail(ICPX_ERR_INVALID, "unknown nn mode %d", mode);
+    if (n == 0) return ICPX_OK;
+    if (!queries || (m > 0 && !targets)) return fail(ICPX_ERR_INVALID, "null queries/targets");
+    if (n > INT32_MAX / 4 || m > INT32_MAX / 4) return fail(ICPX_ERR_UNSUPPORTED, "cloud too large");
+    int dev = 0;
+    ICPX_TRY(resolve_device(device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Workspace& ws = workspace(dev);
+    std::lock_guard<std::mutex> lk(ws.mu);
+
+    const double* d_q = queries;
+    const double* d_t = targets;
+    if (!is_device_ptr(queries)) {
+        ICPX_TRY(ws.q.reserve(sizeof(double) * dim * n));
+        ICPX_HIP(hipMemcpyAsync(ws.q.p, queries, sizeof(double) * dim * n, hipMemcpyHostToDevice, stream));
+        d_q = ws.q.as<double>();
+    }
+    if (m > 0 && !is_device_ptr(targets)) {
+        ICPX_TRY(ws.t.reserve(sizeof(double) * dim * m));
+        ICPX_HIP(hipMemcpyAsync(ws.t.p, targets, sizeof(double) * dim * m, hipMemcpyHostToDevice, stream));
+        d_t = ws.t.as<double>();
+    }
+    const bool idx_dev = is_device_ptr(idx), d2_dev = is_device_ptr(d2);
+    int64_t* d_idx = idx;
+    double* d_d2 = d2;
+    if (idx && !idx_dev) {
+        ICPX_TRY(ws.idx.reserve(sizeof(int64_t) * n));
+        d_idx = ws.idx.as<int64_t>();
+    }
+    if (d2 && !d2_dev) {
+        ICPX_TRY(ws.d2.reserve(sizeof(double) * n));
+        d_d2 = ws.d2.as<double>();
+    }
+
+    bool use_grid = mode == ICPX_NN_GRID ||
+                    (mode == ICPX_NN_AUTO && static_cast<double>(n) * static_cast<double>(m) > 64.0 * 1024 * 1024);
+    if (m == 0) use_grid = false;
+    if (use_grid) {
+        ICPX_TRY(grid_nn_oneshot(dim, d_q, n, d_t, m, d_idx, d_d2, stream));
+    } else {
+        // (query blocks) x (target splits) so that the launch fills the chip
+        const int qblocks = static_cast<int>((n + kNnThreads * kNnQpt - 1) / (kNnThreads * kNnQpt));
+        int splits = (4 * di->cus + qblocks - 1) / qblocks;
+        int max_splits = static_cast<int>((m + kNnTile - 1) / kNnTile);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        int64_t split_len = (m + splits - 1) / splits;
+        split_len = (split_len + kNnTile - 1) / kNnTile * kNnTile;
+        if (split_len < kNnTile) split_len = kNnTile;
+        splits = m > 0 ? static_cast<int>((m + split_len - 1) / split_len) : 1;
+        ICPX_TRY(ws.part_d2.reserve(sizeof(double) * n * splits));
+        ICPX_TRY(ws.part_idx.reserve(sizeof(int32_t) * n * splits));
+        dim3 grid(qblocks, splits);
+        if (dim == 2)
+            hipLaunchKernelGGL(nn_brute_kernel<2>, grid, dim3(kNnThreads), 0, stream, d_q, n, d_t, m, split_len,
+                               ws.part_d2.as<double>(), ws.part_idx.as<int32_t>());
+        else
+            hipLaunchKernelGGL(nn_brute_kernel<3>, grid, dim3(kNnThreads), 0, stream, d_q, n, d_t, m, split_len,
+                               ws.part_d2.as<double>(), ws.part_idx.as<int32_t>());
+        ICPX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(nn_merge_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, n,
+                           splits, ws.part_d2.as<double>(), ws.part_idx.as<int32_t>(), d_idx, d_d2);
+        ICPX_HIP(hipGetLastError());
+    }
+    if (idx && !idx_dev) ICPX_HIP(hipMemcpyAsync(idx, d_idx, sizeof(int64_t) * n, hipMemcpyDeviceToHost, stream));
+    if (d2 && !d2_dev) ICPX_HIP(hipMemcpyAsync(d2, d_d2, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    ICPX_HIP(hipStreamSynchronize(stream));
+    return ICPX_OK;
+}
+
+}  // extern "C"

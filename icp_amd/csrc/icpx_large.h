@@ -1,0 +1,42 @@
+// icpx_large.h — host interface of the multi-kernel ("large cloud") ICP path and of the
+// uniform-grid nearest-neighbour search.  Implemented in icpx_large.hip.
+#pragma once
+
+#include <chrono>
+
+#include "icpx_host.h"
+
+namespace icpx {
+
+struct LargeIcp;
+
+int large_create(int dim, int method, const icpx_params& prm, double clock_to_s, hipStream_t stream,
+                 LargeIcp** out);
+void large_destroy(LargeIcp* lg);
+// ICP::begin + setup() (icp.h:120-133; vanilla.cpp:21-26, vanilla_3d.cpp:71-81, trimmed_3d.cpp:77-87)
+int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* target, int64_t m,
+                const double* guess);
+int large_iterate(LargeIcp* lg);
+// ICPDriver::converge loop (driver.h:63-69): iterations are chained on the stream, termination is
+// decided on the device; the host only polls a done flag every few iterations.
+int large_converge(LargeIcp* lg, const icpx_criteria* crit,
+                   std::chrono::steady_clock::time_point t0, icpx_state* out);
+int large_cost(LargeIcp* lg, double* out);
+int large_transform(LargeIcp* lg, double* out);
+int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost);
+int large_neighbors(LargeIcp* lg, int64_t* idx, double* dist);
+
+// Reusable search structure over one target cloud (device memory).
+struct GridIndex;
+int grid_create(GridIndex** out);
+void grid_destroy(GridIndex* g);
+// d_t: DEVICE pointer, AoS dim x m.  Synchronises the stream once (bounding box read-back).
+int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream);
+// d_q / d_idx / d_d2: DEVICE pointers (idx, d2 may be null).  visited (device u64, may be null)
+// accumulates the number of candidate targets examined.
+int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
+                      unsigned long long* d_visited, hipStream_t stream);
+int grid_nn_oneshot(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m,
+                    int64_t* d_idx, double* d_d2, hipStream_t stream);
+
+}  // namespace icpx

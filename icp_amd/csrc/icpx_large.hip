@@ -1,0 +1,730 @@
+// icpx_large.hip — the multi-kernel ICP path for clouds beyond the fused kernel's limits, and the
+// host side of the uniform-grid nearest-neighbour search.
+//
+// One iteration = 5 launches chained on the stream, no host round trip:
+//   lg_nn      c = step*c (3D, vanilla_3d.cpp:91), exact grid NN of every source point
+//              (vanilla_3d.cpp:30-45), neighbour distance / selection flag (trimmed_3d.cpp:98)
+//   lg_sum1    TREE64 levels 1-2 of the centroid sums (geo.h:33-37 on the selected pairs)
+//   lg_fin1    remaining levels, centroids
+//   lg_sum2    TREE64 levels 1-2 of the cross-covariance (vanilla_3d.cpp:51)
+//   lg_fin2    remaining levels, Kabsch SVD, transform = step*transform (vanilla_3d.cpp:53-66,93),
+//              ICPDriver::should_terminate (driver.h:154-222) -> device-side done flag
+// Every kernel returns at once when the done flag is set, so the host can enqueue iterations in
+// chunks and poll the flag only between chunks.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "icpx_grid.h"
+#include "icpx_large.h"
+#include "icpx_math.h"
+
+namespace icpx {
+
+constexpr int kBlk = 1024;          // threads per reduction block
+constexpr int kSlots = 4;           // points per thread -> 4096 points (64 TREE64 groups) per block
+constexpr int kBlkPts = kBlk * kSlots;
+constexpr int64_t kLargeMaxN = int64_t(1) << 24;  // <= 4096 block partials -> at most 4 tree levels
+
+struct GridIndex {
+    GridParams gp{};
+    int dim = 0;
+    int ncell = 0;
+    DevBuf recs, start, cell_id, counts, keys;
+};
+
+struct LargeDev {
+    PairState st;
+    double step[16];
+    double ca[3], cb[3];
+    double ksel;
+    double cost_sum;
+};
+
+struct LargeIcp {
+    int dim = 0, method = 0;
+    icpx_params prm{};
+    double clock_to_s = 1e-8;
+    hipStream_t stream = nullptr;
+    int64_t n = 0, m = 0;
+    int nblk = 0;
+    GridIndex* grid = nullptr;
+    DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
+    int* h_done = nullptr;  // pinned
+};
+
+// ------------------------------------------------------------------------------------------
+// device kernels
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+template <int D>
+__global__ void lg_init_kernel(LargeDev* dev, const double* guess) {
+    constexpr int XN = (D + 1) * (D + 1);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int e = 0; e < 16; e++) {
+        double g = e < XN ? guess[e] : 0.0;
+        dev->st.transform[e] = g;
+        dev->st.last_transform[e] = g;
+        dev->step[e] = (e < XN && (e % (D + 2)) == 0) ? 1.0 : 0.0;
+    }
+    dev->st.iteration_count = 0;
+    dev->st.have_last = 0;
+    dev->st.done = 0;
+    dev->st.cost = 0.0;
+    dev->st.last_cost = 0.0;
+    dev->st.start_clock = wall_clock64();
+    dev->ksel = 0.0;
+    dev->cost_sum = 0.0;
+}
+
+// NN stage.  SETUP2D: Vanilla::setup's compute_matches on the untransformed source
+// (vanilla.cpp:68-88); otherwise the 3D per-iteration stage.
+template <int D, int METHOD, bool SETUP2D>
+__global__ void __launch_bounds__(256)
+lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
+             int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+             int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
+             double max_distance) {
+    if (respect_done && dev->st.done) return;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double q[D];
+    if (SETUP2D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) q[d] = src[i * D + d];
+    } else {
+        // c = T * c with the step the previous iteration produced (identity after begin)
+        Xf<D> S;
+#pragma unroll
+        for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
+        XfRows<D> sr = xf_rows<D>(S);
+        double c[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
+        xf_apply<D>(sr, c, q);
+#pragma unroll
+        for (int d = 0; d < D; d++) cur[i * D + d] = q[d];
+    }
+    double best;
+    int bi, visited = 0;
+    grid_query<D>(gp, recs, start, q, best, bi, visited);
+    double c = __builtin_sqrt(__builtin_sqrt(best));  // sqrt of kdtree.h:126's Euclidean distance
+    nb_idx[i] = bi;
+    nb_cost[i] = c;
+    sel[i] = (D == 3 && METHOD == ICPX_TRIMMED) ? (c <= max_distance ? 1 : 0) : 1;
+}
+
+// TREE64 levels 1 and 2 over this block's 4096 points.  f(i, vals) gives point i's NV terms.
+template <int NV, typename F>
+ICPX_DEV void block_tree(F&& f, int64_t n, double* __restrict__ part, int nblk, double* gs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
+    const int64_t g_total = (n + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        int64_t i = base + k * kBlk + tid;
+        int64_t g = (base >> 6) + k * (kBlk >> 6) + wave;
+        if (g < g_total) {
+            double vals[NV];
+            if (i < n) {
+                f(i, vals);
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; v++) vals[v] = 0.0;
+            }
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                double s = wave_sum(vals[v]);
+                if (lane == 0) gs[v * 64 + k * (kBlk >> 6) + wave] = s;
+            }
+        }
+    }
+    __syncthreads();
+    if (g_total == 1) {
+        if (tid < NV) part[tid * nblk] = gs[tid * 64];
+    } else if (wave == 0) {
+        int64_t gl = g_total - (base >> 6);  // groups in this block
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            double x = lane < gl ? gs[v * 64 + lane] : 0.0;
+            double s = wave_sum(x);
+            if (lane == 0) part[v * nblk + blockIdx.x] = s;
+        }
+    }
+}
+
+// remaining TREE64 levels over the per-block partials; every thread gets the total.
+ICPX_DEV double fin_tree(const double* __restrict__ part, int nblk, double* lds) {
+    if (nblk == 1) return part[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int G = (nblk + 63) >> 6;
+    for (int g = wave; g < G; g += W) {
+        int j = g * 64 + lane;
+        double x = j < nblk ? part[j] : 0.0;
+        double s = wave_sum(x);
+        if (lane == 0) lds[g] = s;
+    }
+    __syncthreads();
+    double r;
+    if (G == 1) {
+        r = lds[0];
+    } else {
+        double x = lane < G ? lds[lane] : 0.0;
+        r = wave_sum(x);
+    }
+    __syncthreads();
+    return r;
+}
+
+template <int D, int METHOD>
+__global__ void __launch_bounds__(kBlk)
+lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
+               const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
+               const double* __restrict__ nb_cost, const uint8_t* __restrict__ sel, double* __restrict__ part,
+               int* __restrict__ cntp, int nblk) {
+    __shared__ double gs[(2 * D + 1) * 64];
+    __shared__ int wcnt[kBlk / 64];
+    if (respect_done && dev->st.done) return;
+    Xf<D> X;
+#pragma unroll
+    for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+    XfRows<D> xr = xf_rows<D>(X);
+    int cnt = 0;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
+    for (int k = 0; k < kSlots; k++) {
+        int64_t i = base + k * kBlk + threadIdx.x;
+        if (i < n) cnt += sel[i];
+    }
+    block_tree<2 * D + 1>(
+        [&](int64_t i, double (&v)[2 * D + 1]) {
+            double p[D], c[D];
+            if (D == 2) {
+#pragma unroll
+                for (int d = 0; d < D; d++) p[d] = src[i * D + d];
+                xf_apply<D>(xr, p, c);  // a_current = transform * a, vanilla.cpp:33
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
+            }
+            bool s = sel[i] != 0;
+            int64_t j = nb_idx[i];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                v[d] = s ? c[d] : 0.0;
+                v[D + d] = s ? dst[j * D + d] : 0.0;
+            }
+            v[2 * D] = D == 2 ? nb_cost[i] : 0.0;
+        },
+        n, part, nblk, gs);
+    cnt = wave_sum_int(cnt);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kBlk / 64; w++) t += wcnt[w];
+        cntp[blockIdx.x] = t;
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kBlk)
+lg_fin1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, const int* __restrict__ cntp,
+               int nblk) {
+    __shared__ double lds[64];
+    if (respect_done && dev->st.done) return;
+    double s[2 * D + 1];
+    for (int v = 0; v < 2 * D + 1; v++) s[v] = fin_tree(part + static_cast<int64_t>(v) * nblk, nblk, lds);
+    if (threadIdx.x == 0) {
+        long long k = 0;
+        for (int b = 0; b < nblk; b++) k += cntp[b];
+        double kd = static_cast<double>(k);
+        for (int d = 0; d < D; d++) {
+            dev->ca[d] = s[d] / kd;
+            dev->cb[d] = s[D + d] / kd;
+        }
+        dev->ksel = kd;
+        dev->cost_sum = s[2 * D];
+    }
+}
+
+template <int D, int METHOD>
+__global__ void __launch_bounds__(kBlk)
+lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
+               const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
+               const uint8_t* __restrict__ sel, double* __restrict__ part, int nblk) {
+    __shared__ double gs[D * D * 64];
+    if (respect_done && dev->st.done) return;
+    Xf<D> X;
+#pragma unroll
+    for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+    XfRows<D> xr = xf_rows<D>(X);
+    double ca[D], cb[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        ca[d] = dev->ca[d];
+        cb[d] = dev->cb[d];
+    }
+    block_tree<D * D>(
+        [&](int64_t i, double (&v)[D * D]) {
+            double p[D], c[D], b[D];
+            if (D == 2) {
+#pragma unroll
+                for (int d = 0; d < D; d++) p[d] = src[i * D + d];
+                xf_apply<D>(xr, p, c);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
+            }
+            bool s = sel[i] != 0;
+            int64_t j = nb_idx[i];
+#pragma unroll
+            for (int d = 0; d < D; d++) b[d] = dst[j * D + d];
+#pragma unroll
+            for (int r = 0; r < D; r++)
+#pragma unroll
+                for (int cc = 0; cc < D; cc++) v[cc * D + r] = s ? (c[r] - ca[r]) * (b[cc] - cb[cc]) : 0.0;
+        },
+        n, part, nblk, gs);
+}
+
+// setup tail: ICP::calculate_cost of the initial matches, then the loop's first should_terminate
+template <int D>
+__global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx_criteria crit,
+                                       double clock_to_s, double host_elapsed_s) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sum = D == 2 ? dev->cost_sum : 0.0;
+    dev->st.cost = __builtin_sqrt(sum / static_cast<double>(n));  // icp.h:149-155
+    if (check) {
+        double el = host_elapsed_s + static_cast<double>(wall_clock64() - dev->st.start_clock) * clock_to_s;
+        if (should_terminate<D>(crit, dev->st, el)) {
+            dev->st.done = 1;
+        } else {
+            for (int e = 0; e < 16; e++) dev->st.last_transform[e] = dev->st.transform[e];
+            dev->st.last_cost = dev->st.cost;
+            dev->st.have_last = 1;
+        }
+    }
+}
+
+template <int D, int METHOD>
+__global__ void __launch_bounds__(kBlk)
+lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, int nblk, int check,
+               icpx_criteria crit, double clock_to_s, double host_elapsed_s) {
+    __shared__ double lds[64];
+    constexpr int XN = (D + 1) * (D + 1);
+    if (respect_done && dev->st.done) return;
+    double s[D * D];
+    for (int v = 0; v < D * D; v++) s[v] = fin_tree(part + static_cast<int64_t>(v) * nblk, nblk, lds);
+    if (threadIdx.x == 0) {
+        Mat<D> N;
+#pragma unroll
+        for (int e = 0; e < D * D; e++) N.a[e] = s[e];
+        double ca[D], cb[D];
+        for (int d = 0; d < D; d++) {
+            ca[d] = dev->ca[d];
+            cb[d] = dev->cb[d];
+        }
+        Xf<D> step = kabsch<D>(N, ca, cb);
+        Xf<D> X;
+        for (int e = 0; e < XN; e++) X.m[e] = dev->st.transform[e];
+        Xf<D> nx = xf_mul<D>(step, X);
+        for (int e = 0; e < XN; e++) {
+            dev->st.transform[e] = nx.m[e];
+            dev->step[e] = step.m[e];
+        }
+        dev->st.iteration_count += 1;
+        // cost: 2D vanilla's matches never change (vanilla.cpp:80); ICP3 never fills them (Q4)
+        if (check) {
+            double el = host_elapsed_s + static_cast<double>(wall_clock64() - dev->st.start_clock) * clock_to_s;
+            if (should_terminate<D>(crit, dev->st, el)) {
+                dev->st.done = 1;
+            } else {
+                for (int e = 0; e < 16; e++) dev->st.last_transform[e] = dev->st.transform[e];
+                dev->st.last_cost = dev->st.cost;
+                dev->st.have_last = 1;
+            }
+        }
+    }
+}
+
+__global__ void lg_matches_kernel(int64_t n, const int64_t* __restrict__ nb_idx, int64_t* __restrict__ point) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) point[i] = i;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// grid host side
+// ------------------------------------------------------------------------------------------
+
+int grid_create(GridIndex** out) {
+    *out = new (std::nothrow) GridIndex();
+    return *out ? ICPX_OK : fail(ICPX_ERR_NOMEM, "out of host memory");
+}
+
+void grid_destroy(GridIndex* g) {
+    if (!g) return;
+    for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys}) b->release();
+    delete g;
+}
+
+int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream) {
+    g->dim = dim;
+    GridParams& gp = g->gp;
+    std::memset(&gp, 0, sizeof(gp));
+    gp.m = m;
+    for (int d = 0; d < 3; d++) {
+        gp.g[d] = 1;
+        gp.h[d] = 1.0;
+        gp.inv_h[d] = 1.0;
+    }
+    if (m <= 0) {
+        g->ncell = 1;
+        ICPX_TRY(g->start.reserve(sizeof(int) * 2));
+        ICPX_HIP(hipMemsetAsync(g->start.p, 0, sizeof(int) * 2, stream));
+        ICPX_TRY(g->recs.reserve(sizeof(GridRec)));
+        return ICPX_OK;
+    }
+    // 1. bounding box
+    ICPX_TRY(g->keys.reserve(sizeof(unsigned long long) * 6));
+    unsigned long long init[6] = {~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
+    ICPX_HIP(hipMemcpyAsync(g->keys.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    int blocks = static_cast<int>(std::min<int64_t>((m + 255) / 256, 2048));
+    if (dim == 2)
+        hipLaunchKernelGGL(grid_bbox_kernel<2>, dim3(blocks), dim3(256), 0, stream, d_t, m, g->keys.as<unsigned long long>());
+    else
+        hipLaunchKernelGGL(grid_bbox_kernel<3>, dim3(blocks), dim3(256), 0, stream, d_t, m, g->keys.as<unsigned long long>());
+    ICPX_HIP(hipGetLastError());
+    unsigned long long keys[6];
+    ICPX_HIP(hipMemcpyAsync(keys, g->keys.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
+    ICPX_HIP(hipStreamSynchronize(stream));
+    // 2. cell size: about 2 targets per cell over the non-degenerate axes
+    double ext[3] = {0, 0, 0};
+    int nz = 0;
+    double vol = 1.0;
+    bool any = keys[0] != ~0ULL;
+    for (int d = 0; d < dim; d++) {
+        gp.lo[d] = any ? f64_unkey(keys[d]) : 0.0;
+        gp.hi[d] = any ? f64_unkey(keys[3 + d]) : 0.0;
+        ext[d] = gp.hi[d] - gp.lo[d];
+        if (ext[d] > 0.0 && std::isfinite(ext[d])) {
+            nz++;
+            vol *= ext[d];
+        } else {
+            ext[d] = 0.0;
+        }
+    }
+    const double target_cells = std::max<double>(1.0, static_cast<double>(m) / 2.0);
+    double h = 1.0;
+    if (nz > 0) {
+        h = std::pow(vol / target_cells, 1.0 / nz);
+        if (!(h > 0.0) || !std::isfinite(h)) h = 1.0;
+    }
+    const int64_t max_cells = std::min<int64_t>(4 * m + 64, int64_t(1) << 27);
+    for (int attempt = 0; attempt < 64; attempt++) {
+        int64_t total = 1;
+        for (int d = 0; d < dim; d++) {
+            double cnt = ext[d] > 0.0 ? std::floor(ext[d] / h) + 1.0 : 1.0;
+            if (cnt > 2.0e6) cnt = 2.0e6;
+            gp.g[d] = static_cast<int>(cnt);
+            total *= gp.g[d];
+        }
+        if (total <= max_cells) break;
+        h *= 1.26;  // ~ 2^(1/3): halve the cell count per retry in 3D
+    }
+    int64_t total = 1;
+    for (int d = 0; d < dim; d++) {
+        gp.h[d] = h;
+        gp.inv_h[d] = 1.0 / h;
+        total *= gp.g[d];
+    }
+    if (total > max_cells) return fail(ICPX_ERR_UNSUPPORTED, "grid: degenerate cloud extents");
+    gp.rmax = std::max(gp.g[0], std::max(gp.g[1], gp.g[2])) - 1;
+    g->ncell = static_cast<int>(total);
+    // 3. counting sort by cell
+    ICPX_TRY(g->cell_id.reserve(sizeof(int) * m));
+    ICPX_TRY(g->counts.reserve(sizeof(int) * (total + 1)));
+    ICPX_TRY(g->start.reserve(sizeof(int) * (total + 1)));
+    ICPX_TRY(g->recs.reserve(sizeof(GridRec) * m));
+    ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 1), stream));
+    unsigned mb = static_cast<unsigned>((m + 255) / 256);
+    if (dim == 2)
+        hipLaunchKernelGGL(grid_count_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
+    else
+        hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
+    ICPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, stream, g->counts.as<int>(), g->ncell, g->start.as<int>());
+    ICPX_HIP(hipGetLastError());
+    ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 1), stream));  // reuse as cursors
+    if (dim == 2)
+        hipLaunchKernelGGL(grid_scatter_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, m, g->cell_id.as<int>(),
+                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>());
+    else
+        hipLaunchKernelGGL(grid_scatter_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, m, g->cell_id.as<int>(),
+                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>());
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
+                      unsigned long long* d_visited, hipStream_t stream) {
+    if (n <= 0) return ICPX_OK;
+    unsigned nb = static_cast<unsigned>((n + 255) / 256);
+    if (g->dim == 2)
+        hipLaunchKernelGGL(grid_nn_kernel<2>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
+                           g->start.as<int>(), d_idx, d_d2, d_visited);
+    else
+        hipLaunchKernelGGL(grid_nn_kernel<3>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
+                           g->start.as<int>(), d_idx, d_d2, d_visited);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+int grid_nn_oneshot(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
+                    double* d_d2, hipStream_t stream) {
+    GridIndex* g = nullptr;
+    ICPX_TRY(grid_create(&g));
+    int rc = grid_build(g, dim, d_t, m, stream);
+    if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, d_idx, d_d2, nullptr, stream);
+    if (rc == ICPX_OK) {
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    }
+    grid_destroy(g);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// large-path host side
+// ------------------------------------------------------------------------------------------
+
+int large_create(int dim, int method, const icpx_params& prm, double clock_to_s, hipStream_t stream,
+                 LargeIcp** out) {
+    LargeIcp* lg = new (std::nothrow) LargeIcp();
+    if (!lg) return fail(ICPX_ERR_NOMEM, "out of host memory");
+    lg->dim = dim;
+    lg->method = method;
+    lg->prm = prm;
+    lg->clock_to_s = clock_to_s;
+    lg->stream = stream;
+    int rc = grid_create(&lg->grid);
+    if (rc != ICPX_OK) {
+        delete lg;
+        return rc;
+    }
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&lg->h_done), sizeof(int) * 4, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        grid_destroy(lg->grid);
+        delete lg;
+        return fail(ICPX_ERR_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    *out = lg;
+    return ICPX_OK;
+}
+
+void large_destroy(LargeIcp* lg) {
+    if (!lg) return;
+    (void)hipStreamSynchronize(lg->stream);
+    for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
+                      &lg->cntp, &lg->dev})
+        b->release();
+    grid_destroy(lg->grid);
+    if (lg->h_done) (void)hipHostFree(lg->h_done);
+    delete lg;
+}
+
+namespace {
+
+template <int D, int METHOD>
+int enqueue_sums(LargeIcp* lg, int respect_done, bool second) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const int nblk = lg->nblk;
+    if (!second) {
+        hipLaunchKernelGGL((lg_sum1_kernel<D, METHOD>), dim3(nblk), dim3(kBlk), 0, lg->stream, dev, respect_done,
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->n,
+                           lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(),
+                           lg->part.as<double>(), lg->cntp.as<int>(), nblk);
+        ICPX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(lg_fin1_kernel<D>, dim3(1), dim3(kBlk), 0, lg->stream, dev, respect_done,
+                           lg->part.as<double>(), lg->cntp.as<int>(), nblk);
+        ICPX_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL((lg_sum2_kernel<D, METHOD>), dim3(nblk), dim3(kBlk), 0, lg->stream, dev, respect_done,
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->n,
+                           lg->nb_idx.as<int64_t>(), lg->sel.as<uint8_t>(), lg->part.as<double>(), nblk);
+        ICPX_HIP(hipGetLastError());
+    }
+    return ICPX_OK;
+}
+
+template <int D, int METHOD>
+int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    hipLaunchKernelGGL(lg_init_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->guess.as<double>());
+    ICPX_HIP(hipGetLastError());
+    if (D == 2) {
+        unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, true>), dim3(nb), dim3(256), 0, lg->stream, dev, 0,
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
+                           lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
+                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+        ICPX_HIP(hipGetLastError());
+        ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
+    }
+    hipLaunchKernelGGL(lg_setup_finish_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, check, crit,
+                       lg->clock_to_s, host_elapsed_s);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+template <int D, int METHOD>
+int enqueue_iteration(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const int respect = check;
+    if (D == 3) {
+        unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, false>), dim3(nb), dim3(256), 0, lg->stream, dev, respect,
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
+                           lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
+                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+        ICPX_HIP(hipGetLastError());
+    }
+    ICPX_TRY((enqueue_sums<D, METHOD>(lg, respect, false)));
+    ICPX_TRY((enqueue_sums<D, METHOD>(lg, respect, true)));
+    hipLaunchKernelGGL((lg_fin2_kernel<D, METHOD>), dim3(1), dim3(kBlk), 0, lg->stream, dev, respect,
+                       lg->part.as<double>(), lg->nblk, check, crit, lg->clock_to_s, host_elapsed_s);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+#define LG_DISPATCH(fn, lg, ...)                                                             \
+    ((lg)->dim == 2 ? fn<2, ICPX_VANILLA>(lg, __VA_ARGS__)                                   \
+                    : ((lg)->method == ICPX_VANILLA ? fn<3, ICPX_VANILLA>(lg, __VA_ARGS__)   \
+                                                    : fn<3, ICPX_TRIMMED>(lg, __VA_ARGS__)))
+
+icpx_criteria zero_criteria() {
+    icpx_criteria c;
+    std::memset(&c, 0, sizeof(c));
+    return c;
+}
+
+}  // namespace
+
+int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* target, int64_t m,
+                const double* guess) {
+    const int D = lg->dim;
+    if (D == 2 && lg->method == ICPX_TRIMMED)
+        return fail(ICPX_ERR_UNSUPPORTED,
+                    "trimmed ICP2 beyond the fused kernel's limits (n <= 4096, target in LDS) is not implemented yet");
+    if (n <= 0 || m <= 0) return fail(ICPX_ERR_INVALID, "large path needs non-empty clouds");
+    if (n > kLargeMaxN) return fail(ICPX_ERR_UNSUPPORTED, "source cloud above %lld points", (long long)kLargeMaxN);
+    lg->n = n;
+    lg->m = m;
+    lg->nblk = static_cast<int>((n + kBlkPts - 1) / kBlkPts);
+    ICPX_TRY(lg->src.reserve(sizeof(double) * D * n));
+    ICPX_TRY(lg->dst.reserve(sizeof(double) * D * m));
+    ICPX_TRY(lg->cur.reserve(sizeof(double) * D * n));
+    ICPX_TRY(lg->guess.reserve(sizeof(double) * 16));
+    ICPX_TRY(lg->nb_idx.reserve(sizeof(int64_t) * n));
+    ICPX_TRY(lg->nb_cost.reserve(sizeof(double) * n));
+    ICPX_TRY(lg->sel.reserve(n));
+    ICPX_TRY(lg->part.reserve(sizeof(double) * 16 * lg->nblk));
+    ICPX_TRY(lg->cntp.reserve(sizeof(int) * lg->nblk));
+    ICPX_TRY(lg->dev.reserve(sizeof(LargeDev)));
+    ICPX_HIP(hipMemcpyAsync(lg->src.p, source, sizeof(double) * D * n, hipMemcpyDefault, lg->stream));
+    ICPX_HIP(hipMemcpyAsync(lg->dst.p, target, sizeof(double) * D * m, hipMemcpyDefault, lg->stream));
+    ICPX_HIP(hipMemcpyAsync(lg->guess.p, guess, sizeof(double) * (D + 1) * (D + 1), hipMemcpyDefault, lg->stream));
+    // c = a (vanilla_3d.cpp:72): the guess is NOT applied to the running cloud (Q5)
+    ICPX_HIP(hipMemcpyAsync(lg->cur.p, lg->src.p, sizeof(double) * D * n, hipMemcpyDeviceToDevice, lg->stream));
+    ICPX_HIP(hipMemsetAsync(lg->sel.p, 1, n, lg->stream));
+    ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
+    return LG_DISPATCH(enqueue_setup, lg, 0, zero_criteria(), 0.0);
+}
+
+int large_iterate(LargeIcp* lg) { return LG_DISPATCH(enqueue_iteration, lg, 0, zero_criteria(), 0.0); }
+
+int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_clock::time_point t0,
+                   icpx_state* out) {
+    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    // large_begin already ran setup without a check: evaluate the loop's first should_terminate
+    if (lg->dim == 2)
+        hipLaunchKernelGGL(lg_setup_finish_kernel<2>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, 1, *crit,
+                           lg->clock_to_s, elapsed());
+    else
+        hipLaunchKernelGGL(lg_setup_finish_kernel<3>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, 1, *crit,
+                           lg->clock_to_s, elapsed());
+    ICPX_HIP(hipGetLastError());
+    uint64_t enq = 0;
+    int chunk = 4;
+    while (true) {
+        ICPX_HIP(hipMemcpyAsync(lg->h_done, &dev->st.done, sizeof(int), hipMemcpyDeviceToHost, lg->stream));
+        ICPX_HIP(hipStreamSynchronize(lg->stream));
+        if (lg->h_done[0]) break;
+        uint64_t k = static_cast<uint64_t>(chunk);
+        if ((crit->has & ICPX_HAS_MAX_ITER) && enq + k > crit->max_iterations)
+            k = crit->max_iterations > enq ? crit->max_iterations - enq : 1;
+        for (uint64_t j = 0; j < k; j++) ICPX_TRY(LG_DISPATCH(enqueue_iteration, lg, 1, *crit, elapsed()));
+        enq += k;
+        if (chunk < 16) chunk *= 2;
+    }
+    PairState st;
+    ICPX_HIP(hipMemcpyAsync(&st, &dev->st, sizeof(PairState), hipMemcpyDeviceToHost, lg->stream));
+    ICPX_HIP(hipStreamSynchronize(lg->stream));
+    icpx_state res;
+    std::memset(&res, 0, sizeof(res));
+    res.cost = st.cost;
+    res.iteration_count = st.iteration_count;
+    const int XN = (lg->dim + 1) * (lg->dim + 1);
+    for (int e = 0; e < XN; e++) res.transform[e] = st.transform[e];
+    ICPX_HIP(hipMemcpy(out, &res, sizeof(res), hipMemcpyDefault));
+    return ICPX_OK;
+}
+
+int large_cost(LargeIcp* lg, double* out) {
+    ICPX_HIP(hipMemcpyAsync(out, &lg->dev.as<LargeDev>()->st.cost, sizeof(double), hipMemcpyDeviceToHost, lg->stream));
+    ICPX_HIP(hipStreamSynchronize(lg->stream));
+    return ICPX_OK;
+}
+
+int large_transform(LargeIcp* lg, double* out) {
+    const int XN = (lg->dim + 1) * (lg->dim + 1);
+    ICPX_HIP(hipMemcpyAsync(out, lg->dev.as<LargeDev>()->st.transform, sizeof(double) * XN, hipMemcpyDeviceToHost, lg->stream));
+    ICPX_HIP(hipStreamSynchronize(lg->stream));
+    return ICPX_OK;
+}
+
+int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost) {
+    // 2D vanilla only (3D is answered by the caller): matches stay in point order
+    const int64_t n = lg->n;
+    if (point) {
+        DevBuf tmp;
+        ICPX_TRY(tmp.reserve(sizeof(int64_t) * n));
+        hipLaunchKernelGGL(lg_matches_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, lg->stream, n,
+                           lg->nb_idx.as<int64_t>(), tmp.as<int64_t>());
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(point, tmp.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(lg->stream);
+        tmp.release();
+        if (e != hipSuccess) return fail(ICPX_ERR_HIP, "matches copy failed: %s", hipGetErrorString(e));
+    }
+    if (pair) ICPX_HIP(hipMemcpyAsync(pair, lg->nb_idx.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream));
+    if (cost) ICPX_HIP(hipMemcpyAsync(cost, lg->nb_cost.p, sizeof(double) * n, hipMemcpyDefault, lg->stream));
+    ICPX_HIP(hipStreamSynchronize(lg->stream));
+    return ICPX_OK;
+}
+
+int large_neighbors(LargeIcp* lg, int64_t* idx, double* dist) {
+    const int64_t n = lg->n;
+    if (idx) ICPX_HIP(hipMemcpyAsync(idx, lg->nb_idx.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream));
+    if (dist) ICPX_HIP(hipMemcpyAsync(dist, lg->nb_cost.p, sizeof(double) * n, hipMemcpyDefault, lg->stream));
+    ICPX_HIP(hipStreamSynchronize(lg->stream));
+    return ICPX_OK;
+}
+
+}  // namespace icpx

@@ -1,0 +1,446 @@
+// icpx_math.h — small f64 dense algebra used by every ICP kernel (device side).
+//
+// All of it runs on ONE lane: the 2x2 / 3x3 two-sided Jacobi SVD, the Kabsch step, the transform
+// composition and the driver's termination test.  Arithmetic is plain IEEE f64 with contraction
+// off (the translation unit is built with -ffp-contract=off), in the operand order documented in
+// DESIGN.md, so that results are reproducible bit for bit.
+//
+// Reference call sites this stands in for:
+//   Eigen::JacobiSVD(N, FullU|FullV), R = V U^T, reflection fix, t = cb - R ca
+//     lib/icp/impl/vanilla.cpp:50-63, trimmed.cpp:75-90, vanilla_3d.cpp:53-66, trimmed_3d.cpp:59-72
+//   transform = step * transform        vanilla.cpp:65, trimmed.cpp:92, vanilla_3d.cpp:93
+//   ICPDriver::should_terminate         include/icp/driver.h:154-222
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/icpx/icpx.h"
+
+#define ICPX_DEV __device__ __forceinline__
+
+namespace icpx {
+
+constexpr double kDblMin = 2.2250738585072014e-308;
+constexpr double kDblEps = 2.220446049250313e-16;
+constexpr double kPi = 3.14159265358979323846;
+
+ICPX_DEV double dabs(double x) { return __builtin_fabs(x); }
+ICPX_DEV double dmax(double a, double b) { return a < b ? b : a; }
+
+struct Rot {
+    double c, s;
+};
+
+// Jacobi rotation that diagonalises the symmetric 2x2 [[x, y], [y, z]]
+ICPX_DEV Rot make_jacobi(double x, double y, double z) {
+    Rot r;
+    double deno = 2.0 * dabs(y);
+    if (deno < kDblMin) {
+        r.c = 1.0;
+        r.s = 0.0;
+    } else {
+        double tau = (x - z) / deno;
+        double w = __builtin_sqrt(tau * tau + 1.0);
+        double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        double sign_t = t > 0.0 ? 1.0 : -1.0;
+        double n = 1.0 / __builtin_sqrt(t * t + 1.0);
+        r.s = -sign_t * (y / dabs(y)) * dabs(t) * n;
+        r.c = n;
+    }
+    return r;
+}
+
+ICPX_DEV Rot rot_mul(Rot a, Rot b) { return Rot{a.c * b.c - a.s * b.s, a.c * b.s + a.s * b.c}; }
+ICPX_DEV Rot rot_t(Rot a) { return Rot{a.c, -a.s}; }
+ICPX_DEV void rot_apply(double& x, double& y, Rot j) {
+    double xi = x, yi = y;
+    x = j.c * xi + j.s * yi;
+    y = -j.s * xi + j.c * yi;
+}
+
+// column-major D x D
+template <int D>
+struct Mat {
+    double a[D * D];
+    ICPX_DEV double& operator()(int r, int c) { return a[c * D + r]; }
+    ICPX_DEV double operator()(int r, int c) const { return a[c * D + r]; }
+    ICPX_DEV void set_identity() {
+#pragma unroll
+        for (int i = 0; i < D * D; i++) a[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) a[i * D + i] = 1.0;
+    }
+};
+
+template <int D>
+ICPX_DEV void rows_rotate(Mat<D>& m, int p, int q, Rot j) {
+    if (j.c == 1.0 && j.s == 0.0) return;
+#pragma unroll
+    for (int c = 0; c < D; c++) rot_apply(m.a[c * D + p], m.a[c * D + q], j);
+}
+// columns p,q rotated by j^T (Eigen's applyOnTheRight(p, q, j))
+template <int D>
+ICPX_DEV void cols_rotate(Mat<D>& m, int p, int q, Rot j) {
+    Rot jt = rot_t(j);
+    if (jt.c == 1.0 && jt.s == 0.0) return;
+#pragma unroll
+    for (int r = 0; r < D; r++) rot_apply(m.a[p * D + r], m.a[q * D + r], jt);
+}
+
+// two-sided Jacobi SVD, full U and V, singular values sorted descending
+template <int D>
+ICPX_DEV void jacobi_svd(const Mat<D>& in, Mat<D>& U, double* S, Mat<D>& V) {
+    const double precision = 2.0 * kDblEps;
+    double scale = 0.0;
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < D * D; i++) {
+        double v = dabs(in.a[i]);
+        if (!(v <= 1.7976931348623157e308)) finite = false;  // inf or NaN
+        if (v > scale) scale = v;
+    }
+    U.set_identity();
+    V.set_identity();
+    if (!finite) {
+        double nan = __builtin_nan("");
+#pragma unroll
+        for (int i = 0; i < D; i++) S[i] = nan;
+#pragma unroll
+        for (int i = 0; i < D * D; i++) U.a[i] = V.a[i] = nan;
+        return;
+    }
+    if (scale == 0.0) scale = 1.0;
+    Mat<D> w;
+#pragma unroll
+    for (int i = 0; i < D * D; i++) w.a[i] = in.a[i] / scale;
+    double max_diag = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) max_diag = dmax(max_diag, dabs(w(i, i)));
+
+    bool finished = false;
+    while (!finished) {
+        finished = true;
+#pragma unroll
+        for (int p = 1; p < D; ++p) {
+#pragma unroll
+            for (int q = 0; q < p; ++q) {
+                double threshold = dmax(kDblMin, precision * max_diag);
+                if (dabs(w(p, q)) > threshold || dabs(w(q, p)) > threshold) {
+                    finished = false;
+                    // 2x2 kernel: first a rotation that makes the block symmetric, then Jacobi
+                    double m00 = w(p, p), m01 = w(p, q), m10 = w(q, p), m11 = w(q, q);
+                    Rot rot1;
+                    double t = m00 + m11;
+                    double d = m10 - m01;
+                    if (dabs(d) < kDblMin) {
+                        rot1.s = 0.0;
+                        rot1.c = 1.0;
+                    } else {
+                        double u = t / d;
+                        double tmp = __builtin_sqrt(1.0 + u * u);
+                        rot1.s = 1.0 / tmp;
+                        rot1.c = u / tmp;
+                    }
+                    if (!(rot1.c == 1.0 && rot1.s == 0.0)) {
+                        rot_apply(m00, m10, rot1);
+                        rot_apply(m01, m11, rot1);
+                    }
+                    Rot j_right = make_jacobi(m00, m01, m11);
+                    Rot j_left = rot_mul(rot1, rot_t(j_right));
+                    rows_rotate<D>(w, p, q, j_left);
+                    cols_rotate<D>(U, p, q, rot_t(j_left));
+                    cols_rotate<D>(w, p, q, j_right);
+                    cols_rotate<D>(V, p, q, j_right);
+                    max_diag = dmax(max_diag, dmax(dabs(w(p, p)), dabs(w(q, q))));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double a = w(i, i);
+        S[i] = dabs(a);
+        if (a < 0.0) {
+#pragma unroll
+            for (int r = 0; r < D; r++) U(r, i) = -U(r, i);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) S[i] *= scale;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        // largest remaining singular value moves to position i (first one wins ties)
+        int pos = i;
+        double best = S[i];
+#pragma unroll
+        for (int k = i + 1; k < D; k++)
+            if (S[k] > best) {
+                best = S[k];
+                pos = k;
+            }
+        if (best == 0.0) break;
+#pragma unroll
+        for (int k = i + 1; k < D; k++) {
+            if (pos == k) {
+                double ts = S[i];
+                S[i] = S[k];
+                S[k] = ts;
+#pragma unroll
+                for (int r = 0; r < D; r++) {
+                    double tu = U(r, i);
+                    U(r, i) = U(r, k);
+                    U(r, k) = tu;
+                    double tv = V(r, i);
+                    V(r, i) = V(r, k);
+                    V(r, k) = tv;
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+ICPX_DEV double det(const Mat<D>& m) {
+    if constexpr (D == 2) {
+        return m(0, 0) * m(1, 1) - m(1, 0) * m(0, 1);
+    } else {
+        double h0 = m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1));
+        double h1 = m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0));
+        double h2 = m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
+        return h0 - h1 + h2;
+    }
+}
+
+template <int D>
+ICPX_DEV Mat<D> v_ut(const Mat<D>& V, const Mat<D>& U) {
+    Mat<D> R;
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            double s = V(i, 0) * U(j, 0);
+#pragma unroll
+            for (int k = 1; k < D; k++) s += V(i, k) * U(j, k);
+            R(i, j) = s;
+        }
+    return R;
+}
+
+// (D+1)x(D+1) column-major rigid transform
+template <int D>
+struct Xf {
+    double m[(D + 1) * (D + 1)];
+    ICPX_DEV double& operator()(int r, int c) { return m[c * (D + 1) + r]; }
+    ICPX_DEV double operator()(int r, int c) const { return m[c * (D + 1) + r]; }
+    ICPX_DEV void set_identity() {
+#pragma unroll
+        for (int i = 0; i < (D + 1) * (D + 1); i++) m[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i <= D; i++) m[i * (D + 1) + i] = 1.0;
+    }
+};
+
+// a * b  (linear = La Lb, translation = La tb + ta; sums left to right)
+template <int D>
+ICPX_DEV Xf<D> xf_mul(const Xf<D>& a, const Xf<D>& b) {
+    Xf<D> r;
+    r.set_identity();
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            double s = a(i, 0) * b(0, j);
+#pragma unroll
+            for (int k = 1; k < D; k++) s += a(i, k) * b(k, j);
+            r(i, j) = s;
+        }
+        double s = a(i, 0) * b(0, D);
+#pragma unroll
+        for (int k = 1; k < D; k++) s += a(i, k) * b(k, D);
+        r(i, D) = s + a(i, D);
+    }
+    return r;
+}
+
+// x * p = (L p) + t, sums left to right.  `x` is given as its first D rows flattened
+// row-major into registers by the caller (see XfRows) to keep the hot loops free of indexing.
+template <int D>
+struct XfRows {
+    double l[D][D];
+    double t[D];
+};
+template <int D>
+ICPX_DEV XfRows<D> xf_rows(const Xf<D>& x) {
+    XfRows<D> r;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+#pragma unroll
+        for (int j = 0; j < D; j++) r.l[i][j] = x(i, j);
+        r.t[i] = x(i, D);
+    }
+    return r;
+}
+template <int D>
+ICPX_DEV void xf_apply(const XfRows<D>& x, const double* p, double* out) {
+    double tmp[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        double s = x.l[i][0] * p[0];
+#pragma unroll
+        for (int k = 1; k < D; k++) s += x.l[i][k] * p[k];
+        tmp[i] = s + x.t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; i++) out[i] = tmp[i];
+}
+
+// Kabsch step from the cross-covariance N and the two centroids
+template <int D>
+ICPX_DEV Xf<D> kabsch(const Mat<D>& N, const double* ca, const double* cb) {
+    Mat<D> U, V;
+    double S[D];
+    jacobi_svd<D>(N, U, S, V);
+    Mat<D> R = v_ut<D>(V, U);
+    if (det<D>(R) < 0) {
+#pragma unroll
+        for (int r = 0; r < D; r++) V(r, D - 1) = -V(r, D - 1);
+        R = v_ut<D>(V, U);
+    }
+    Xf<D> step;
+    step.set_identity();
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+#pragma unroll
+        for (int j = 0; j < D; j++) step(i, j) = R(i, j);
+        double s = R(i, 0) * ca[0];
+#pragma unroll
+        for (int k = 1; k < D; k++) s += R(i, k) * ca[k];
+        step(i, D) = cb[i] - s;
+    }
+    return step;
+}
+
+// |rotation angle| between two transforms: Rotation2Dd(Rc Rl^T).smallestAngle() in 2D,
+// AngleAxisd(Rc Rl^T).angle() in 3D (driver.h:196-210)
+template <int D>
+ICPX_DEV double rotation_angle(const double* cur, const double* last) {
+    constexpr int L = D + 1;
+    if constexpr (D == 2) {
+        double m00 = cur[0 * L + 0] * last[0 * L + 0] + cur[1 * L + 0] * last[1 * L + 0];
+        double m10 = cur[0 * L + 1] * last[0 * L + 0] + cur[1 * L + 1] * last[1 * L + 0];
+        double angle = atan2(m10, m00);
+        double tmp = fmod(angle, 2.0 * kPi);
+        if (tmp > kPi) tmp -= 2.0 * kPi;
+        else if (tmp < -kPi) tmp += 2.0 * kPi;
+        return tmp;
+    } else {
+        double mat[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double s = cur[0 * L + i] * last[0 * L + j];
+#pragma unroll
+                for (int k = 1; k < 3; k++) s += cur[k * L + i] * last[k * L + j];
+                mat[i][j] = s;
+            }
+        // rotation matrix -> quaternion (x, y, z, w); explicit cases keep everything in registers
+        double qx, qy, qz, qw;
+        double t = mat[0][0] + mat[1][1] + mat[2][2];
+        if (t > 0.0) {
+            t = __builtin_sqrt(t + 1.0);
+            qw = 0.5 * t;
+            t = 0.5 / t;
+            qx = (mat[2][1] - mat[1][2]) * t;
+            qy = (mat[0][2] - mat[2][0]) * t;
+            qz = (mat[1][0] - mat[0][1]) * t;
+        } else {
+            int i = 0;
+            if (mat[1][1] > mat[0][0]) i = 1;
+            double mii = i == 0 ? mat[0][0] : mat[1][1];
+            if (mat[2][2] > mii) i = 2;
+            if (i == 0) {  // (i, j, k) = (0, 1, 2)
+                t = __builtin_sqrt(mat[0][0] - mat[1][1] - mat[2][2] + 1.0);
+                qx = 0.5 * t;
+                t = 0.5 / t;
+                qw = (mat[2][1] - mat[1][2]) * t;
+                qy = (mat[1][0] + mat[0][1]) * t;
+                qz = (mat[2][0] + mat[0][2]) * t;
+            } else if (i == 1) {  // (1, 2, 0)
+                t = __builtin_sqrt(mat[1][1] - mat[2][2] - mat[0][0] + 1.0);
+                qy = 0.5 * t;
+                t = 0.5 / t;
+                qw = (mat[0][2] - mat[2][0]) * t;
+                qz = (mat[2][1] + mat[1][2]) * t;
+                qx = (mat[0][1] + mat[1][0]) * t;
+            } else {  // (2, 0, 1)
+                t = __builtin_sqrt(mat[2][2] - mat[0][0] - mat[1][1] + 1.0);
+                qz = 0.5 * t;
+                t = 0.5 / t;
+                qw = (mat[1][0] - mat[0][1]) * t;
+                qx = (mat[0][2] + mat[2][0]) * t;
+                qy = (mat[1][2] + mat[2][1]) * t;
+            }
+        }
+        double nrm = __builtin_sqrt(qx * qx + qy * qy + qz * qz);
+        if (nrm != 0.0) return 2.0 * atan2(nrm, dabs(qw));
+        return 0.0;
+    }
+}
+
+// Device image of one pair's ICP state; lives in global memory between launches.
+struct PairState {
+    double transform[16];
+    double last_transform[16];
+    double cost;
+    double last_cost;
+    uint64_t iteration_count;
+    int32_t have_last;
+    int32_t done;
+    uint64_t start_clock;  // wall_clock64() when converge started
+    uint64_t _pad;
+};
+
+// ICPDriver::should_terminate (driver.h:154-222).  elapsed_s: seconds since converge() began.
+template <int D>
+ICPX_DEV bool should_terminate(const icpx_criteria& c, const PairState& s, double elapsed_s) {
+    if ((c.has & ICPX_HAS_MIN_ITER) && s.iteration_count < c.min_iterations) return false;
+    if ((c.has & ICPX_HAS_MAX_ITER) && s.iteration_count >= c.max_iterations) return true;
+    if ((c.has & ICPX_HAS_STOP_COST) && s.cost < c.stop_cost) return true;
+    if ((c.has & ICPX_HAS_TIME_LIMIT) && elapsed_s > c.time_limit_s) return true;
+    if (!s.have_last) return false;
+    double delta_cost = s.cost - s.last_cost;
+    if ((c.has & ICPX_HAS_ABS_TOL) && dabs(delta_cost) < c.absolute_cost_tolerance) return true;
+    double rel = dabs(delta_cost) / s.cost;
+    if ((c.has & ICPX_HAS_REL_TOL) && rel < c.relative_cost_tolerance) return true;
+    if (c.has & ICPX_HAS_TRANSFORM_TOL) {
+        double angle = rotation_angle<D>(s.transform, s.last_transform);
+        double tn = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            double d = s.transform[D * (D + 1) + i] - s.last_transform[D * (D + 1) + i];
+            tn += d * d;
+        }
+        tn = __builtin_sqrt(tn);
+        if (dabs(angle) < c.angle_tolerance_rad && tn < c.translation_tolerance) return true;
+    }
+    return false;
+}
+
+// ---- wave-level helpers -------------------------------------------------------------------
+
+// 64-lane xor butterfly sum: every lane ends with the same value; the association order is the
+// one DESIGN.md calls TREE64 (v[l] + v[l^32], then ^16, ... ^1).
+ICPX_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+ICPX_DEV int wave_sum_int(int v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+
+}  // namespace icpx

@@ -1,0 +1,97 @@
+// icpx_nn.h — stand-alone correspondence kernels (device side).
+//
+//  * nn_brute_kernel: LDS-tiled brute force over (query block) x (target split); partial results
+//    are merged by nn_merge_kernel.  Arithmetic and tie-break are those of
+//    Trimmed::compute_matches (lib/icp/impl/trimmed.cpp:95-109).
+//  * uniform-grid search (build + query) for large clouds: icpx_grid.h.
+#pragma once
+
+#include "icpx_math.h"
+
+namespace icpx {
+
+constexpr int kNnTile = 1024;   // targets per LDS tile
+constexpr int kNnThreads = 256;
+constexpr int kNnQpt = 2;       // queries per lane
+
+// grid = (query blocks, target splits).  q, t: AoS.  part_d2/part_idx: [splits][n].
+template <int D>
+__global__ void __launch_bounds__(kNnThreads)
+nn_brute_kernel(const double* __restrict__ q, int64_t n, const double* __restrict__ t, int64_t m,
+                int64_t split_len, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
+    __shared__ double tile[D][kNnTile];
+    const int tid = threadIdx.x;
+    const int64_t qbase = static_cast<int64_t>(blockIdx.x) * (kNnThreads * kNnQpt);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
+    const int64_t t1 = t0 + split_len < m ? t0 + split_len : m;
+
+    double qq[kNnQpt][D];
+    double best[kNnQpt];
+    int bidx[kNnQpt];
+#pragma unroll
+    for (int k = 0; k < kNnQpt; k++) {
+        int64_t i = qbase + tid + k * kNnThreads;
+        best[k] = __builtin_inf();
+        bidx[k] = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) qq[k][d] = i < n ? q[i * D + d] : 0.0;
+    }
+    for (int64_t base = t0; base < t1; base += kNnTile) {
+        const int cnt = static_cast<int>(t1 - base < kNnTile ? t1 - base : kNnTile);
+        __syncthreads();
+        for (int j = tid; j < cnt; j += kNnThreads) {
+#pragma unroll
+            for (int d = 0; d < D; d++) tile[d][j] = t[(base + j) * D + d];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < cnt; j++) {
+            double tc[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) tc[d] = tile[d][j];
+#pragma unroll
+            for (int k = 0; k < kNnQpt; k++) {
+                double df = tc[0] - qq[k][0];
+                double dist = df * df;
+#pragma unroll
+                for (int d = 1; d < D; d++) {
+                    df = tc[d] - qq[k][d];
+                    dist = dist + df * df;
+                }
+                bool lt = dist < best[k];
+                best[k] = lt ? dist : best[k];
+                bidx[k] = lt ? static_cast<int>(base + j) : bidx[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kNnQpt; k++) {
+        int64_t i = qbase + tid + k * kNnThreads;
+        if (i < n) {
+            part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = best[k];
+            part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = bidx[k];
+        }
+    }
+}
+
+// splits are ordered by target index and each partial already holds its lowest index, so a
+// strict < in split order keeps the lexicographic (d2, index) minimum.
+__global__ void nn_merge_kernel(int64_t n, int splits, const double* __restrict__ part_d2,
+                                const int32_t* __restrict__ part_idx, int64_t* __restrict__ idx,
+                                double* __restrict__ d2) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double best = part_d2[i];
+    int32_t bi = part_idx[i];
+    for (int s = 1; s < splits; s++) {
+        double d = part_d2[static_cast<int64_t>(s) * n + i];
+        if (d < best) {
+            best = d;
+            bi = part_idx[static_cast<int64_t>(s) * n + i];
+        }
+    }
+    if (idx) idx[i] = bi;
+    if (d2) d2[i] = best;
+}
+
+}  // namespace icpx

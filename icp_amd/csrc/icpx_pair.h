@@ -1,0 +1,514 @@
+// icpx_pair.h — the fused, device-resident ICP loop for scan-sized clouds: ONE workgroup runs a
+// whole ICPDriver::converge() for one scan pair.
+//
+// Per iteration, without leaving the kernel (reference: lib/icp/impl/{vanilla,trimmed,vanilla_3d,
+// trimmed_3d}.cpp iterate(); include/icp/driver.h:51-72,154-222):
+//   transform apply  ->  brute-force NN against the target cloud staged in LDS (SoA, broadcast
+//   reads; each lane owns up to QPT queries in registers)  ->  selection (2D trimmed: bitonic
+//   sort of (cost, point) keys in LDS; 3D trimmed: distance threshold)  ->  centroid and
+//   cross-covariance sums in the TREE64 order (wave butterfly, then one butterfly over the <= 64
+//   group sums)  ->  single-lane Jacobi SVD / Kabsch  ->  transform composition, cost,
+//   should_terminate.
+//
+// Limits of this kernel: n <= 4096 source points (<= 64 TREE64 groups) and a target cloud that
+// fits LDS (checked on the host, icpx_capi.hip).  Larger clouds take the multi-kernel path.
+#pragma once
+
+#include "icpx_math.h"
+
+namespace icpx {
+
+constexpr int kPairMaxN = 4096;
+constexpr int kGsStride = 64;   // level-1 group sums per value
+constexpr int kGsValues = 10;   // up to 9 covariance terms (+ spare)
+constexpr int kBcDoubles = 48;  // broadcast area
+
+struct PairBatch {
+    int dim;
+    int method;
+    const double* src;         // concatenated source clouds (AoS)
+    const int64_t* src_off;    // n_pairs+1 offsets in points (device)
+    const double* dst;
+    const int64_t* dst_off;
+    const double* guesses;     // n_pairs x (D+1)^2 or nullptr
+    double* cur;               // 3D running cloud c, same offsets as src (persistent)
+    int64_t* m_point;          // matches / neighbours, same offsets as src; may be nullptr
+    int64_t* m_pair;
+    double* m_cost;
+    int32_t* pair_tmp;         // n_total scratch (pair by point), nullptr iff m_point is
+    PairState* states;         // n_pairs
+    icpx_state* out_states;    // n_pairs, device staging (may be nullptr)
+    icpx_criteria crit;
+    double overlap_rate;
+    double max_distance;
+    double clock_to_s;         // seconds per wall_clock64() tick
+    double host_elapsed_s;     // time already spent on the host side of converge()
+    uint64_t max_steps;        // iterations this launch may run
+    int32_t do_setup;          // run begin()/setup() first
+    int32_t check;             // evaluate should_terminate (converge) or not (iterate)
+    int32_t lds_target_cap;    // padded target capacity the launch reserved in LDS
+    int32_t lds_sort_cap;      // npad reserved for the sort area (2D trimmed)
+};
+
+template <int D>
+struct LdsView {
+    double* t[3];    // target SoA
+    double* gs;      // kGsValues x kGsStride
+    double* bc;      // broadcast
+    uint64_t* skey;  // sort keys
+    uint32_t* sval;  // sort values
+};
+
+template <int D>
+ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap) {
+    LdsView<D> v;
+    double* p = base;
+    for (int d = 0; d < D; d++) {
+        v.t[d] = p;
+        p += tcap;
+    }
+    if (D == 2) v.t[2] = nullptr;
+    v.gs = p;
+    p += kGsValues * kGsStride;
+    v.bc = p;
+    p += kBcDoubles;
+    v.skey = reinterpret_cast<uint64_t*>(p);
+    v.sval = reinterpret_cast<uint32_t*>(v.skey + scap);
+    return v;
+}
+
+inline size_t pair_lds_bytes(int dim, int tcap, int scap) {
+    return sizeof(double) * (static_cast<size_t>(dim) * tcap + kGsValues * kGsStride + kBcDoubles) +
+           static_cast<size_t>(scap) * 12;
+}
+
+// brute-force NN of QPT register-resident queries against the LDS target cloud.
+// d2 = ((dx*dx) + dy*dy) + dz*dz with dx = target - query (trimmed.cpp:101), strict <,
+// ascending j  =>  lexicographic min of (d2, j).
+template <int D, int QPT>
+ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m, double (&best)[QPT],
+                     int (&bidx)[QPT]) {
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        best[k] = __builtin_inf();
+        bidx[k] = 0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < m; j++) {
+        double tc[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) tc[d] = L.t[d][j];
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            double df = tc[0] - q[k][0];
+            double dist = df * df;
+#pragma unroll
+            for (int d = 1; d < D; d++) {
+                df = tc[d] - q[k][d];
+                dist = dist + df * df;
+            }
+            bool lt = dist < best[k];
+            best[k] = lt ? dist : best[k];
+            bidx[k] = lt ? j : bidx[k];
+        }
+    }
+}
+
+// TREE64 sum of NV values per point.  f(k, vals) fills the NV contributions of point tid + k*T
+// (0.0 where the point does not exist or is not selected).  Every thread receives the totals.
+template <int NV, int QPT, typename F>
+ICPX_DEV void block_sum(F&& f, int n, int T, double* gs, double (&out)[NV]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = T >> 6;
+    const int G = (n + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        int g = k * W + wave;
+        if (g < G) {
+            double vals[NV];
+            f(k, vals);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                double s = wave_sum(vals[v]);
+                if (lane == 0) gs[v * kGsStride + g] = s;
+            }
+        }
+    }
+    __syncthreads();
+    if (G <= 1) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) out[v] = G == 1 ? gs[v * kGsStride] : 0.0;
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            double x = lane < G ? gs[v * kGsStride + lane] : 0.0;
+            out[v] = wave_sum(x);
+        }
+    }
+    __syncthreads();
+}
+
+template <int QPT>
+ICPX_DEV int block_count(const int (&flags)[QPT], int T, double* gs_as_scratch) {
+    int* cnt = reinterpret_cast<int*>(gs_as_scratch);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = T >> 6;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < QPT; k++) c += flags[k];
+    c = wave_sum_int(c);
+    if (lane == 0) cnt[wave] = c;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < W; w++) tot += cnt[w];
+    __syncthreads();
+    return tot;
+}
+
+// in-LDS bitonic sort of npad (power of two) (key, val) pairs, ascending lexicographic
+ICPX_DEV void bitonic_sort(uint64_t* key, uint32_t* val, int npad, int T) {
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npad; i += T) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t ka = key[i], kb = key[ixj];
+                    uint32_t va = val[i], vb = val[ixj];
+                    bool a_gt_b = ka > kb || (ka == kb && va > vb);
+                    bool up = (i & k) == 0;
+                    if (a_gt_b == up) {
+                        key[i] = kb;
+                        key[ixj] = ka;
+                        val[i] = vb;
+                        val[ixj] = va;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int D, int METHOD, int QPT, int TMAX>
+__global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    constexpr int L1 = D + 1;
+    constexpr int XN = L1 * L1;
+    const int p = blockIdx.x;
+    const int T = blockDim.x;
+    const int tid = threadIdx.x;
+    const int64_t s0 = pb.src_off[p], d0 = pb.dst_off[p];
+    const int n = static_cast<int>(pb.src_off[p + 1] - s0);
+    const int m = static_cast<int>(pb.dst_off[p + 1] - d0);
+    const double* __restrict__ src = pb.src + s0 * D;
+    const double* __restrict__ dst = pb.dst + d0 * D;
+    PairState* st = pb.states + p;
+    LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap);
+    const bool empty = (n == 0 || m == 0);
+
+    // ---- stage the target cloud into LDS as SoA ----
+    for (int j = tid; j < m; j += T) {
+#pragma unroll
+        for (int d = 0; d < D; d++) L.t[d][j] = dst[static_cast<int64_t>(j) * D + d];
+    }
+
+    // ---- per-thread point slots ----
+    double a[QPT][D];    // 2D: source points; 3D: running cloud c
+    double cost[QPT];    // match cost (2D) / neighbour distance (3D)
+    int pair[QPT];
+    bool valid[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        int i = tid + k * T;
+        valid[k] = i < n;
+        cost[k] = 0.0;
+        pair[k] = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            double v = 0.0;
+            if (valid[k]) {
+                if (D == 3 && !pb.do_setup) v = pb.cur[(s0 + i) * D + d];
+                else v = src[static_cast<int64_t>(i) * D + d];
+            }
+            a[k][d] = v;
+        }
+    }
+
+    // ---- state ----
+    if (tid == 0) {
+        if (pb.do_setup) {
+            // ICP::begin, icp.h:120-133
+            for (int e = 0; e < XN; e++) {
+                double g = pb.guesses ? pb.guesses[static_cast<int64_t>(p) * XN + e]
+                                      : ((e % (L1 + 1)) == 0 ? 1.0 : 0.0);
+                st->transform[e] = g;
+                st->last_transform[e] = g;
+            }
+            st->iteration_count = 0;
+            st->have_last = 0;
+            st->done = 0;
+            st->last_cost = 0.0;
+            st->start_clock = wall_clock64();
+        }
+        for (int e = 0; e < XN; e++) L.bc[e] = st->transform[e];
+    }
+    __syncthreads();
+
+    bool sorted_matches = false;
+
+    // current transform in registers (uniform)
+    Xf<D> X;
+#pragma unroll
+    for (int e = 0; e < XN; e++) X.m[e] = L.bc[e];
+
+    double state_cost = 0.0;
+    if (pb.do_setup) {
+        // ---- method setup(): initial matches (2D) ----
+        if (D == 2 && !empty) {
+            double q[QPT][D];
+            if (METHOD == ICPX_VANILLA) {
+                // vanilla.cpp:80 — the query is the UNTRANSFORMED source point
+#pragma unroll
+                for (int k = 0; k < QPT; k++)
+#pragma unroll
+                    for (int d = 0; d < D; d++) q[k][d] = a[k][d];
+            } else {
+                XfRows<D> xr = xf_rows<D>(X);
+#pragma unroll
+                for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
+            }
+            double best[QPT];
+            nn_lds<D, QPT>(q, L, m, best, pair);
+#pragma unroll
+            for (int k = 0; k < QPT; k++) {
+                if (METHOD == ICPX_VANILLA) cost[k] = __builtin_sqrt(__builtin_sqrt(best[k]));  // vanilla.cpp:84 on kdtree.h:126
+                else cost[k] = best[k];                                                        // trimmed.cpp:104
+                if (!valid[k]) cost[k] = 0.0;
+            }
+        }
+        // ICP::calculate_cost, icp.h:149-155
+        double tot[1];
+        block_sum<1, QPT>([&](int k, double (&v)[1]) { v[0] = (D == 2 && valid[k]) ? cost[k] : 0.0; },
+                          n, T, L.gs, tot);
+        state_cost = __builtin_sqrt(tot[0] / static_cast<double>(n));
+        if (tid == 0) st->cost = state_cost;
+    } else {
+        state_cost = st->cost;
+        if (D == 2 && METHOD == ICPX_VANILLA && pb.m_pair) {
+            // resumed launch: matches never change (vanilla.cpp:80), reload them
+#pragma unroll
+            for (int k = 0; k < QPT; k++)
+                if (valid[k]) {
+                    pair[k] = static_cast<int>(pb.m_pair[s0 + tid + k * T]);
+                    cost[k] = pb.m_cost[s0 + tid + k * T];
+                }
+        }
+    }
+
+    // ---- ICPDriver::converge loop, driver.h:63-69 ----
+    uint64_t steps = 0;
+    while (true) {
+        if (tid == 0) {
+            int stop = 0;
+            if (pb.check) {
+                double el = pb.host_elapsed_s +
+                            static_cast<double>(wall_clock64() - st->start_clock) * pb.clock_to_s;
+                if (should_terminate<D>(pb.crit, *st, el)) {
+                    stop = 1;
+                    st->done = 1;
+                }
+            }
+            if (!stop && steps >= pb.max_steps) stop = 2;
+            if (!stop) {
+                // last_state = state
+                for (int e = 0; e < XN; e++) st->last_transform[e] = st->transform[e];
+                st->last_cost = st->cost;
+                st->have_last = 1;
+            }
+            reinterpret_cast<int*>(L.bc + 40)[0] = stop;
+        }
+        __syncthreads();
+        int stop = reinterpret_cast<int*>(L.bc + 40)[0];
+        __syncthreads();
+        if (stop) break;
+        steps++;
+
+        if (!empty) {
+            // ================= iterate() =================
+            double cur[QPT][D];
+            int sel[QPT];
+            int k_sel = n;
+            if (D == 2) {
+                XfRows<D> xr = xf_rows<D>(X);
+#pragma unroll
+                for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
+                if (METHOD == ICPX_TRIMMED) {
+                    double best[QPT];
+                    nn_lds<D, QPT>(cur, L, m, best, pair);
+#pragma unroll
+                    for (int k = 0; k < QPT; k++) cost[k] = valid[k] ? best[k] : 0.0;
+                    // trimming step, trimmed.cpp:55-58: order by (cost, point), keep the first new_n
+                    const int npad = pb.lds_sort_cap;
+                    for (int i = tid; i < npad; i += T) {
+                        L.skey[i] = ~0ULL;
+                        L.sval[i] = static_cast<uint32_t>(i);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < QPT; k++)
+                        if (valid[k]) L.skey[tid + k * T] = static_cast<uint64_t>(__double_as_longlong(cost[k]));
+                    __syncthreads();
+                    bitonic_sort(L.skey, L.sval, npad, T);
+                    sorted_matches = true;
+                    long long new_n = static_cast<long long>(pb.overlap_rate * static_cast<double>(n));
+                    if (new_n < 1) new_n = 1;
+                    if (new_n > n) new_n = n;
+                    k_sel = static_cast<int>(new_n);
+                    uint64_t kth = L.skey[k_sel - 1];
+                    uint32_t vth = L.sval[k_sel - 1];
+#pragma unroll
+                    for (int k = 0; k < QPT; k++) {
+                        uint64_t kk = static_cast<uint64_t>(__double_as_longlong(cost[k]));
+                        uint32_t vv = static_cast<uint32_t>(tid + k * T);
+                        sel[k] = valid[k] && (kk < kth || (kk == kth && vv <= vth));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < QPT; k++) sel[k] = valid[k];
+                }
+            } else {
+                // 3D: nearest_neighbor(c), vanilla_3d.cpp:30-45
+#pragma unroll
+                for (int k = 0; k < QPT; k++)
+#pragma unroll
+                    for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
+                double best[QPT];
+                nn_lds<D, QPT>(cur, L, m, best, pair);
+#pragma unroll
+                for (int k = 0; k < QPT; k++) {
+                    cost[k] = __builtin_sqrt(__builtin_sqrt(best[k]));  // vanilla_3d.cpp:41 on kdtree.h:126
+                    sel[k] = valid[k] && (METHOD == ICPX_VANILLA || cost[k] <= pb.max_distance);  // trimmed_3d.cpp:98
+                }
+                if (METHOD == ICPX_TRIMMED) k_sel = block_count<QPT>(sel, T, L.gs);
+            }
+
+            // matched target coordinates
+            double bp[QPT][D];
+#pragma unroll
+            for (int k = 0; k < QPT; k++)
+#pragma unroll
+                for (int d = 0; d < D; d++) bp[k][d] = sel[k] ? L.t[d][pair[k]] : 0.0;
+
+            // pass 1: centroids (+ cost sum for 2D)
+            constexpr int NV1 = 2 * D + 1;
+            double s1[NV1];
+            block_sum<NV1, QPT>(
+                [&](int k, double (&v)[NV1]) {
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
+                        v[d] = sel[k] ? cur[k][d] : 0.0;
+                        v[D + d] = bp[k][d];
+                    }
+                    v[2 * D] = (D == 2 && valid[k]) ? cost[k] : 0.0;
+                },
+                n, T, L.gs, s1);
+            double ca[D], cb[D];
+            const double kd = static_cast<double>(k_sel);
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                ca[d] = s1[d] / kd;
+                cb[d] = s1[D + d] / kd;
+            }
+
+            // pass 2: cross-covariance N = sum (a - ca)(b - cb)^T
+            double s2[D * D];
+            block_sum<D * D, QPT>(
+                [&](int k, double (&v)[D * D]) {
+#pragma unroll
+                    for (int r = 0; r < D; r++)
+#pragma unroll
+                        for (int c = 0; c < D; c++)
+                            v[c * D + r] = sel[k] ? (cur[k][r] - ca[r]) * (bp[k][c] - cb[c]) : 0.0;
+                },
+                n, T, L.gs, s2);
+
+            if (tid == 0) {
+                Mat<D> N;
+#pragma unroll
+                for (int e = 0; e < D * D; e++) N.a[e] = s2[e];
+                Xf<D> step = kabsch<D>(N, ca, cb);
+                Xf<D> nx = xf_mul<D>(step, X);
+                for (int e = 0; e < XN; e++) {
+                    L.bc[e] = nx.m[e];
+                    L.bc[16 + e] = step.m[e];
+                    st->transform[e] = nx.m[e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < XN; e++) X.m[e] = L.bc[e];
+            if (D == 3) {
+                // c = T * c, vanilla_3d.cpp:91
+                Xf<D> S;
+#pragma unroll
+                for (int e = 0; e < XN; e++) S.m[e] = L.bc[16 + e];
+                XfRows<D> sr = xf_rows<D>(S);
+#pragma unroll
+                for (int k = 0; k < QPT; k++) xf_apply<D>(sr, cur[k], a[k]);
+            }
+            if (D == 2 && METHOD == ICPX_TRIMMED) state_cost = __builtin_sqrt(s1[2 * D] / static_cast<double>(n));
+            __syncthreads();
+        }
+        if (tid == 0) {
+            st->iteration_count += 1;
+            st->cost = state_cost;
+        }
+    }
+
+    // ---- publish ----
+    if (D == 3 && pb.cur) {
+#pragma unroll
+        for (int k = 0; k < QPT; k++)
+            if (valid[k])
+#pragma unroll
+                for (int d = 0; d < D; d++) pb.cur[(s0 + tid + k * T) * D + d] = a[k][d];
+    }
+    if (pb.m_point) {
+        if (D == 3) {
+            // Neighbors of the last iterate (debug view); ICP3 matches stay zero (Q4)
+#pragma unroll
+            for (int k = 0; k < QPT; k++)
+                if (valid[k]) {
+                    pb.m_pair[s0 + tid + k * T] = pair[k];
+                    pb.m_cost[s0 + tid + k * T] = cost[k];
+                    pb.m_point[s0 + tid + k * T] = tid + k * T;
+                }
+        } else if (!sorted_matches) {
+#pragma unroll
+            for (int k = 0; k < QPT; k++)
+                if (valid[k]) {
+                    pb.m_point[s0 + tid + k * T] = tid + k * T;
+                    pb.m_pair[s0 + tid + k * T] = pair[k];
+                    pb.m_cost[s0 + tid + k * T] = cost[k];
+                }
+        } else {
+            // Trimmed leaves matches sorted by cost (trimmed.cpp:55-56); LDS still holds the order
+#pragma unroll
+            for (int k = 0; k < QPT; k++)
+                if (valid[k]) pb.pair_tmp[s0 + tid + k * T] = pair[k];
+            __syncthreads();
+            for (int r = tid; r < n; r += T) {
+                uint32_t pt = L.sval[r];
+                pb.m_point[s0 + r] = pt;
+                pb.m_pair[s0 + r] = pb.pair_tmp[s0 + pt];
+                pb.m_cost[s0 + r] = __longlong_as_double(static_cast<long long>(L.skey[r]));
+            }
+        }
+    }
+    if (tid == 0 && pb.out_states) {
+        icpx_state* o = pb.out_states + p;
+        o->cost = st->cost;
+        o->iteration_count = st->iteration_count;
+        for (int e = 0; e < 16; e++) o->transform[e] = e < XN ? st->transform[e] : 0.0;
+    }
+}
+
+}  // namespace icpx

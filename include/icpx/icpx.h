@@ -1,0 +1,189 @@
+/*
+ * icpx.h — the Eigen-free C ABI of the MI355X (gfx950) ICP engine.
+ *
+ * This is the drop-in boundary for cornellev/icp's hot path
+ *   NN correspondence -> (trimmed) selection -> centroid + cross-covariance ->
+ *   2x2 / 3x3 Kabsch SVD -> transform update -> ICPDriver convergence loop.
+ * The reference has no process/device boundary there (everything is one C++ thread), so the
+ * entry points below are what a binding of the reference's public classes calls; each one names
+ * the reference interface it stands in for (paths relative to the reference checkout).
+ * include/icp/ holds the C++ classes (icp::ICP2/ICP3, icp::ICPDriver, ...) written on top of
+ * it; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - clouds: `const double*` to Dim x n COLUMN-MAJOR data, i.e. x0 y0 (z0) x1 ... — exactly
+ *     icp::PointCloud<Dim>::data() (include/icp/geo.h:26-29).
+ *   - transforms: (Dim+1) x (Dim+1) column-major — icp::RBTransform<Dim>::matrix().data().
+ *   - every cloud/transform/output pointer may be a HOST pointer or a DEVICE (HIP) pointer; the
+ *     library looks at the pointer's attributes and copies accordingly.  Inputs are always
+ *     copied (ICP::begin deep-copies, include/icp/icp.h:125-126).
+ *   - all functions return ICPX_OK (0) or an error code; icpx_last_error() gives the text.
+ *     Nothing throws, nothing aborts.  A handle is not thread-safe (the reference's instances
+ *     are not either); different handles may be used from different threads.
+ *   - all arithmetic is IEEE f64, unfused (no FMA contraction), in the reference's operand order.
+ *
+ * Deterministic tie-break (documented rule): the nearest neighbour of a query is the
+ * lexicographic minimum of (d2, target index) with d2 = sum over axes, in axis order, of
+ * (target - query)^2.  This is bit-for-bit Trimmed::compute_matches
+ * (lib/icp/impl/trimmed.cpp:95-109) and the brute force the reference's kd-tree test treats as
+ * ground truth (tests/test.cpp:53-64); the reference kd-tree (include/algo/kdtree.h) can differ
+ * from it only on exact ties of sqrt(d2).
+ */
+#ifndef ICPX_H
+#define ICPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICPX_VERSION 10000 /* 1.0.0 */
+
+enum icpx_status {
+    ICPX_OK = 0,
+    ICPX_ERR_INVALID = 1,     /* bad argument (null pointer, dim not 2/3, negative size ...) */
+    ICPX_ERR_HIP = 2,         /* a HIP runtime call failed                                     */
+    ICPX_ERR_NOMEM = 3,       /* device or host allocation failed                              */
+    ICPX_ERR_STATE = 4,       /* call order violated (iterate before begin, icp.h:42-43)       */
+    ICPX_ERR_UNSUPPORTED = 5, /* valid request this build does not implement                   */
+    ICPX_ERR_NO_DEVICE = 6    /* no gfx950 device visible                                      */
+};
+
+/* ICP<Dim>::methods registry names (lib/icp/icp.cpp:17-27) */
+enum icpx_method {
+    ICPX_VANILLA = 0, /* "vanilla": Vanilla (2D, vanilla.cpp) / Vanilla3d (vanilla_3d.cpp) */
+    ICPX_TRIMMED = 1  /* "trimmed": Trimmed (2D, trimmed.cpp) / Trimmed3d (trimmed_3d.cpp) */
+};
+
+enum icpx_nn_mode {
+    ICPX_NN_AUTO = 0,  /* brute force for small clouds, uniform grid for large ones */
+    ICPX_NN_BRUTE = 1, /* LDS-tiled brute force                                     */
+    ICPX_NN_GRID = 2   /* exact uniform-grid search                                 */
+};
+
+/* What icp::Config carries for these methods (include/icp/config.h) plus placement. */
+typedef struct icpx_params {
+    double overlap_rate; /* Config "overlap_rate" — Trimmed(2D), trimmed.cpp:28, default 0.9   */
+    double max_distance; /* Config "max_distance" — Trimmed3d, trimmed_3d.cpp:27, default 1.0  */
+    int32_t nn_mode;     /* enum icpx_nn_mode                                                   */
+    int32_t device;      /* HIP device ordinal; -1 = the calling thread's current device        */
+    void* stream;        /* hipStream_t to run on; NULL = the null stream                       */
+} icpx_params;
+
+/* ICPDriver's optional termination criteria (include/icp/driver.h:80-151, 226-233). */
+enum icpx_has {
+    ICPX_HAS_MIN_ITER = 1,      /* set_min_iterations          driver.h:80  */
+    ICPX_HAS_MAX_ITER = 2,      /* set_max_iterations          driver.h:90  */
+    ICPX_HAS_STOP_COST = 4,     /* set_stop_cost               driver.h:101 */
+    ICPX_HAS_REL_TOL = 8,       /* set_relative_cost_tolerance driver.h:113 */
+    ICPX_HAS_ABS_TOL = 16,      /* set_absolute_cost_tolerance driver.h:124 */
+    ICPX_HAS_TRANSFORM_TOL = 32,/* set_transform_tolerance     driver.h:138 */
+    ICPX_HAS_TIME_LIMIT = 64    /* set_time_limit              driver.h:149 */
+};
+
+typedef struct icpx_criteria {
+    uint32_t has; /* bit set of enum icpx_has */
+    uint32_t _pad;
+    uint64_t min_iterations;
+    uint64_t max_iterations;
+    double stop_cost;
+    double relative_cost_tolerance;
+    double absolute_cost_tolerance;
+    double angle_tolerance_rad;
+    double translation_tolerance;
+    double time_limit_s;
+} icpx_criteria;
+
+/* ICPDriver::ConvergenceState (driver.h:24-33) */
+typedef struct icpx_state {
+    double cost;
+    uint64_t iteration_count;
+    double transform[16]; /* first (dim+1)^2 entries, column-major */
+} icpx_state;
+
+typedef struct icpx_ctx* icpx_handle;
+
+/* Library-level ------------------------------------------------------------------------- */
+
+/* No reference counterpart (the reference has no device).  Checks that `device` (-1 = current)
+ * is a gfx950 GPU and warms the HIP runtime.  Optional: every entry point initialises lazily. */
+int icpx_init(int device);
+
+int icpx_version(void);
+
+/* Text of the calling thread's most recent error ("" when none). */
+const char* icpx_last_error(void);
+
+/* Defaults as the reference's constructors read them from an empty Config. */
+void icpx_default_params(icpx_params* p);
+
+/* Instance life cycle ------------------------------------------------------------------- */
+
+/* ICP<Dim>::from_method(name, config) (include/icp/icp.h:95-102) and the concrete
+ * constructors Vanilla/Trimmed/Vanilla3d/Trimmed3d(const Config&).  dim in {2,3}. */
+int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out);
+
+/* ~ICP() (icp.h:116) */
+int icpx_destroy(icpx_handle h);
+
+/* ICP<Dim>::begin(source, target, guess) (icp.h:120-133) including the method's setup():
+ * vanilla.cpp:21-26, trimmed.cpp:31-36 (initial matches), vanilla_3d.cpp:71-81,
+ * trimmed_3d.cpp:77-87 (running cloud c = a, search structure on b). */
+int icpx_begin(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
+               const double* guess);
+
+/* ICP<Dim>::iterate() (icp.h:141): vanilla.cpp:28-66, trimmed.cpp:38-93,
+ * vanilla_3d.cpp:83-96, trimmed_3d.cpp:89-116.  One device-side iteration, no host round trip
+ * of any per-point data. */
+int icpx_iterate(icpx_handle h);
+
+/* ICP<Dim>::calculate_cost() (icp.h:149-155) */
+int icpx_cost(icpx_handle h, double* out);
+
+/* ICP<Dim>::current_transform() (icp.h:158-160); out: (dim+1)^2 doubles, column-major */
+int icpx_transform(icpx_handle h, double* out);
+
+/* ICP<Dim>::get_matches() (icp.h:167-169); each array has n entries (any may be NULL).
+ * As in the reference: Trimmed (2D) leaves them sorted by cost (trimmed.cpp:55-56; order here
+ * is (cost, point)); the 3D methods never fill them (all zero). */
+int icpx_matches(icpx_handle h, int64_t* point, int64_t* pair, double* cost);
+
+/* Source / target sizes given to the last begin/converge. */
+int icpx_sizes(icpx_handle h, int64_t* n, int64_t* m);
+
+/* No public reference counterpart: the Neighbors{distances, indices} that
+ * Vanilla3d::nearest_neighbor (vanilla_3d.cpp:30-45) produced in the last iterate(), for
+ * per-iteration index parity checks.  3D only; arrays of n entries (any may be NULL). */
+int icpx_debug_neighbors(icpx_handle h, int64_t* indices, double* distances);
+
+/* ICPDriver<Dim>::converge(source, target, guess) (driver.h:51-72) with should_terminate
+ * (driver.h:154-222) evaluated on the device: begin + the whole iterate loop are ONE call, the
+ * host reads back only the final ConvergenceState.  After it returns, icpx_cost/transform/
+ * matches refer to the final iteration, as they would on the reference's instance. */
+int icpx_converge(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
+                  const double* guess, const icpx_criteria* criteria, icpx_state* out);
+
+/* Batched ICPDriver::converge over independent scan pairs (trajectory / loop-closure
+ * workloads; no reference counterpart beyond a caller's for-loop, e.g. bench/bench.cpp:56-60).
+ * Pair p uses source[source_offsets[p] .. source_offsets[p+1]) (offsets in POINTS, n_pairs+1
+ * entries, HOST memory) and likewise for target.  guesses: n_pairs x (dim+1)^2 column-major, or
+ * NULL for identity.  out_states: n_pairs entries (host or device memory).  All pairs run on
+ * params->device; shard across devices by calling once per device with a slice. */
+int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t n_pairs,
+                        const double* source, const int64_t* source_offsets,
+                        const double* target, const int64_t* target_offsets,
+                        const double* guesses, const icpx_criteria* criteria,
+                        icpx_state* out_states);
+
+/* Stand-alone correspondence query: the arithmetic of Trimmed::compute_matches
+ * (trimmed.cpp:95-109) / KdTree::search (kdtree.h:79-89) under the documented tie-break.
+ * idx: n x int64 target indices; d2: n x f64 squared distances (either may be NULL).
+ * mode: enum icpx_nn_mode.  device/stream as in icpx_params. */
+int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+            int64_t* idx, double* d2, int mode, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPX_H */

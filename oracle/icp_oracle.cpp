@@ -693,7 +693,14 @@ struct Icp : IcpBase {
     // icp.h:149-155
     double cost() const override {
         std::vector<double> c(static_cast<size_t>(n));
-        for (int64_t i = 0; i < n; i++) c[i] = matches[i].cost;
+        if (prm.sum_mode == ORC_SUM_SEQUENTIAL) {
+            // the reference walks `matches` in its current order (sorted by cost after
+            // Trimmed::iterate, trimmed.cpp:55-56)
+            for (int64_t i = 0; i < n; i++) c[i] = matches[i].cost;
+        } else {
+            // device order: every point keeps its own position in the tree
+            for (int64_t i = 0; i < n; i++) c[matches[i].point] = matches[i].cost;
+        }
         double sum = sum_mode(c, prm.sum_mode);
         return std::sqrt(sum / static_cast<double>(n));
     }
