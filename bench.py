@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the ICP hot path on MI355X.
+
+Workload (BASELINE.json config 5, "batch of independent synthetic 2D/3D scan pairs", one shard per
+GPU, weak scaling): every rank converges 1024 scan pairs per step —
+  512 2D pairs, n = m = 1024, trimmed ICP2 (overlap 0.9)            [config 2's method]
+  512 3D pairs, n = m = 4096, vanilla ICP3 (point-to-point, 3x3 SVD) [config 3's method]
+with ICPDriver criteria max_iterations = 50, transform tolerance (1e-4 rad, 1e-4).  One "step" =
+icpx_converge_batch over the rank's whole shard (inputs resident in HBM before the clock starts)
+followed by the RCCL all_gather of the per-pair results when N > 1.
+
+Metric: NN correspondence queries/s = source points answered by nearest-neighbour steps per second,
+summed over all ranks; converged scan pairs/s is printed in the same JSON line.
+
+roofline: dominant kernel = the fused 3D pair kernel; algorithmic work = 8 flops per
+(query, target) pair evaluated ((3*Dim - 1)), measured with events on the launch stream.
+cpu_baseline: the CPU oracle in reference order (kd-tree NN, std::sort, sequential sums), one core,
+on a bounded sample of the same pairs (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PAIRS_2D, N_2D = 512, 1024
+PAIRS_3D, N_3D = 512, 4096
+MAX_ITER, TOL = 50, (1e-4, 1e-4)
+FP64_PEAK_TFLOPS = 78.6  # MI355X vector FP64, FMA counted as 2 flops (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="pairs per dim timed on the CPU")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import icp_amd
+    from icp_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    icp_amd._lib.check(icp_amd._lib.load().icpx_init(local_rank))
+
+    # ---- this rank's shard of the batch (pair ids are global: rank r owns [r*512, (r+1)*512)) ----
+    ids = np.arange(rank * PAIRS_2D, (rank + 1) * PAIRS_2D)
+    s2, t2, off2, _ = synth.config5_pairs(ids, 2, N_2D)
+    ids3 = np.arange(rank * PAIRS_3D, (rank + 1) * PAIRS_3D)
+    s3, t3, off3, _ = synth.config5_pairs(ids3, 3, N_3D)
+    d_s2, d_t2 = torch.from_numpy(s2).to(dev), torch.from_numpy(t2).to(dev)
+    d_s3, d_t3 = torch.from_numpy(s3).to(dev), torch.from_numpy(t3).to(dev)
+    out2 = torch.zeros(PAIRS_2D * 18, dtype=torch.float64, device=dev)  # icpx_state = 144 B
+    out3 = torch.zeros(PAIRS_3D * 18, dtype=torch.float64, device=dev)
+    gathered = torch.zeros(world * (PAIRS_2D + PAIRS_3D) * 18, dtype=torch.float64, device=dev) if world > 1 else None
+    crit = icp_amd.make_criteria(max_iterations=MAX_ITER, transform_tol=TOL)
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    k3_ms = []
+
+    def step(timed_kernel=False):
+        icp_amd.converge_batch(2, "trimmed", d_s2, off2, d_t2, off2, crit, out_states=out2,
+                               device=local_rank, stream=stream)
+        if timed_kernel:
+            ev[0].record()
+        icp_amd.converge_batch(3, "vanilla", d_s3, off3, d_t3, off3, crit, out_states=out3,
+                               device=local_rank, stream=stream)
+        if timed_kernel:
+            ev[1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, torch.cat([out2, out3]))
+        if timed_kernel:
+            torch.cuda.synchronize()
+            k3_ms.append(ev[0].elapsed_time(ev[1]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed_kernel=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- work accounting from the results (deterministic across steps) ----
+    st2 = out2.cpu().numpy().view(np.dtype([("cost", "f8"), ("it", "u8"), ("T", "f8", 16)]))
+    st3 = out3.cpu().numpy().view(np.dtype([("cost", "f8"), ("it", "u8"), ("T", "f8", 16)]))
+    it2, it3 = st2["it"].astype(np.int64), st3["it"].astype(np.int64)
+    # NN steps: trimmed ICP2 matches once in setup (trimmed.cpp:31-36) and once per iterate;
+    # vanilla ICP3 once per iterate (vanilla_3d.cpp:85)
+    q2 = int(((it2 + 1) * N_2D).sum())
+    q3 = int((it3 * N_3D).sum())
+    queries = torch.tensor([q2 + q3, PAIRS_2D + PAIRS_3D], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(queries, op=dist.ReduceOp.SUM)
+    total_q, total_pairs = float(queries[0].item()), float(queries[1].item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        k3 = float(np.mean(k3_ms)) if k3_ms else float("nan")
+        flops3 = float((it3 * (8.0 * N_3D * N_3D)).sum())
+        achieved = flops3 / (k3 * 1e-3) / 1e12
+        line = {
+            "metric": "nn_correspondence_queries_per_s",
+            "value": total_q / (elapsed / args.steps),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "converged_pairs_per_s": total_pairs / (elapsed / args.steps),
+            "config": {
+                "workload": "BASELINE config 5 shard per GPU: 512 2D pairs (n=m=1024, trimmed ICP2, "
+                            "overlap 0.9) + 512 3D pairs (n=m=4096, vanilla ICP3), ICPDriver "
+                            "max_iterations=50, transform tolerance (1e-4, 1e-4); results gathered with RCCL",
+                "pairs_per_gpu": PAIRS_2D + PAIRS_3D,
+                "mean_iterations_2d": float(it2.mean()),
+                "mean_iterations_3d": float(it3.mean()),
+                "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
+            },
+            "roofline": {
+                "bound": "valu_fp64",
+                "kernel": "pair_kernel<3,vanilla,8,512> (fused 3D converge, one workgroup per pair)",
+                "achieved": achieved,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS,
+                "frac_of_unfused_peak": achieved / (FP64_PEAK_TFLOPS / 2),
+                "launch_ms": k3,
+                "flops_per_launch": flops3,
+                "traffic": None,
+            },
+        }
+        if not args.no_extras and world == 1:
+            line["extras"] = extras(torch, icp_amd, synth, dev, local_rank, stream)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(s2, t2, off2, s3, t3, off3, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(torch, icp_amd, synth, dev, local_rank, stream):
+    """Side measurements of the other single-GPU configs (not the headline value)."""
+    from icp_amd import io as iio
+    ex = {}
+    g = os.path.join(ROOT, "tests", "golden", "ex_data")
+    # config 2: ex_data scan1, trimmed ICP2, single pair (latency of one converge call, host data)
+    a = iio.parse_lidar_scan(os.path.join(g, "scan1", "first.csv"))
+    b = iio.parse_lidar_scan(os.path.join(g, "scan1", "second.csv"))
+    drv = icp_amd.ICPDriver(icp_amd.ICP2.from_method("trimmed", device=local_rank))
+    drv.set_max_iterations(50)
+    drv.set_transform_tolerance(0.1 * np.pi / 180, 0.01)
+    r = drv.converge(a, b)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r = drv.converge(a, b)
+    ex["c2_scan1_trimmed_converge_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    ex["c2_scan1_iterations"] = r.iteration_count
+    # config 3: queen.ply, vanilla ICP3
+    q = iio.read_ply_vertices(os.path.join(g, "ply", "queen.ply"))
+    qt = iio.read_ply_vertices(os.path.join(g, "ply", "queen_transformed.ply"))
+    drv3 = icp_amd.ICPDriver(icp_amd.ICP3.from_method("vanilla", device=local_rank))
+    drv3.set_max_iterations(100)
+    drv3.set_transform_tolerance(1e-4, 1e-4)
+    r = drv3.converge(qt, q)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        r = drv3.converge(qt, q)
+    ex["c3_queen_vanilla3d_converge_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+    ex["c3_queen_iterations"] = r.iteration_count
+    # config 4: 1M x 1M grid NN, one correspondence step, inputs and outputs resident in HBM
+    src, tgt, _, _ = synth.config4(1_000_000)
+    d_q, d_t = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    idx = torch.zeros(len(src), dtype=torch.int64, device=dev)
+    d2 = torch.zeros(len(src), dtype=torch.float64, device=dev)
+    icp_amd.nearest_neighbors(d_q, d_t, icp_amd.NN_GRID, device=local_rank, stream=stream, out_idx=idx, out_d2=d2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        icp_amd.nearest_neighbors(d_q, d_t, icp_amd.NN_GRID, device=local_rank, stream=stream, out_idx=idx, out_d2=d2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    ex["c4_grid_nn_1m_build_plus_query_ms"] = dt * 1e3
+    ex["c4_grid_nn_1m_queries_per_s"] = len(src) / dt
+    return ex
+
+
+def cpu_baseline(s2, t2, off2, s3, t3, off3, sample):
+    """The oracle in reference order on one host core, on the first `sample` pairs of each kind."""
+    from oracle import binding as ob
+    crit = ob.make_criteria(max_iterations=MAX_ITER, transform_tol=TOL)
+    k2, k3 = min(sample, PAIRS_2D), min(sample, PAIRS_3D)
+    queries = 0
+    t0 = time.perf_counter()
+    o2 = ob.OracleICP(2, "trimmed")  # brute-force NN + std::sort, as trimmed.cpp
+    for p in range(k2):
+        r = o2.converge(s2[off2[p]:off2[p + 1]], t2[off2[p]:off2[p + 1]], None, crit)
+        queries += (r.iteration_count + 1) * N_2D
+    o3 = ob.OracleICP(3, "vanilla")  # kd-tree NN, as vanilla_3d.cpp
+    for p in range(k3):
+        r = o3.converge(s3[off3[p]:off3[p + 1]], t3[off3[p]:off3[p + 1]], None, crit)
+        queries += r.iteration_count * N_3D
+    dt = time.perf_counter() - t0
+    return {
+        "value": queries / dt,
+        "unit": "queries/s",
+        "pairs_per_s": (k2 + k3) / dt,
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {k2} 2D pairs + first {k3} 3D pairs of rank 0's shard, {dt:.1f} s of CPU time; "
+                  "oracle in reference order (brute-force NN + std::sort for trimmed ICP2, kd-tree NN for "
+                  "vanilla ICP3, sequential sums), g++ -O3 -DNDEBUG",
+    }
+
+
+if __name__ == "__main__":
+    main()
