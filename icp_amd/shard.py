@@ -1,0 +1,30 @@
+"""Multi-GPU plumbing: independent scan pairs shard across ranks (one process per GPU); the only
+exchange is one gather of the per-pair results (icpx_state records, 144 B each) — RCCL over xGMI on
+GPUs, gloo in the CPU tests.  No collective touches the data path."""
+from __future__ import annotations
+
+
+def shard_range(n_pairs: int, rank: int, world: int):
+    """Contiguous block of pairs owned by `rank`: pair p -> rank floor(p * world / n_pairs)."""
+    lo = (n_pairs * rank + world - 1) // world
+    hi = (n_pairs * (rank + 1) + world - 1) // world
+    return lo, hi
+
+
+def gather_states(local, n_pairs: int, rank: int, world: int):
+    """All ranks receive the (n_pairs, 18) f64 table of icpx_state records.  `local` holds this
+    rank's rows; shards may be ragged, so rows are padded to the largest shard for the
+    all_gather and trimmed afterwards."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return local
+    sizes = [shard_range(n_pairs, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.zeros((world * cap, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    rows = [out[r * cap: r * cap + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
+    return torch.cat(rows)

@@ -1,0 +1,148 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ob():
+    """The CPU oracle binding (test infrastructure)."""
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def scans():
+    from icp_amd import io as iio
+    return {k: (iio.parse_lidar_scan(f"{GOLDEN}/ex_data/scan{k}/first.csv"),
+                iio.parse_lidar_scan(f"{GOLDEN}/ex_data/scan{k}/second.csv")) for k in (1, 2, 3)}
+
+
+@pytest.fixture(scope="session")
+def queen():
+    """(source, target) as tests/test_ply.cpp uses them: queen_transformed -> queen."""
+    from icp_amd import io as iio
+    return (iio.read_ply_vertices(f"{GOLDEN}/ex_data/ply/queen_transformed.ply"),
+            iio.read_ply_vertices(f"{GOLDEN}/ex_data/ply/queen.ply"))
+
+
+@pytest.fixture(scope="session")
+def traces():
+    with open(os.path.join(GOLDEN, "traces.json")) as f:
+        raw = json.load(f)
+    out = {}
+    for k, v in raw.items():
+        if k.startswith("_"):
+            continue
+        d1 = int(round(len(v["transform"]) ** 0.5))
+        out[k] = {
+            "iterations": v["iterations"],
+            "cost": float.fromhex(v["cost"]),
+            "transform": np.array([float.fromhex(x) for x in v["transform"]]).reshape(d1, d1),
+            "trace_cost": np.array([float.fromhex(x) for x in v["trace_cost"]]),
+            "trace_transform": np.array([[float.fromhex(x) for x in t] for t in v["trace_transform"]]).reshape(-1, d1, d1),
+        }
+    return out
+
+
+BENCH_CRIT = dict(max_iterations=50, transform_tol=(0.1 * np.pi / 180, 0.01))  # bench/bench.cpp:109-113
+PLY_CRIT = dict(max_iterations=100, transform_tol=(1e-4, 1e-4))               # tests/test_ply.cpp:22-23
+TEST_CRIT = dict(max_iterations=100, transform_tol=(0.1 * np.pi / 180, 0.1))  # tests/test.cpp:87-88
+
+
+def rot2(deg):
+    a = np.radians(deg)
+    return np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+
+
+def rot3_zyx(dx, dy, dz):
+    """(rot_z * rot_y * rot_x).toRotationMatrix(), tests/test3d.cpp:109"""
+    ax, ay, az = np.radians([dx, dy, dz])
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def reference_cases_2d():
+    """The six cases of the reference's test_icp_generic (tests/test.cpp:83-216) as
+    (name, a, b, expected_R(2x2), expected_t, trans_eps, rad_eps, max_iterations or None)."""
+    TE, RE = 0.5, 0.01
+    cases = []
+    cases.append(("single_point", np.array([[0., 0.]]), np.array([[100., 0.]]), rot2(0), [100, 0], TE, RE, 10))
+    a = np.array([[0., 0.], [100., 100.]])
+    cases.append(("identity", a, a.copy(), rot2(0), [0, 0], TE, RE, None))
+    for deg in range(10):
+        a = np.array([[-100., -100.], [100., 100.]])
+        cases.append((f"rot3a_{deg}", a, a @ rot2(deg).T, rot2(deg), [0, 0], TE, RE, None))
+    for deg in range(10):
+        a = np.array([[0., 0.], [1., 0.]])
+        cases.append((f"rot3b_{deg}", a, a @ rot2(deg).T, rot2(deg), [0, 0], TE, RE, None))
+    cases.append(("translation", np.array([[0., 0.], [0., 100.]]), np.array([[100., 0.], [100., 100.]]),
+                  rot2(0), [100, 0], TE, RE, None))
+    a = np.array([[0., 0.], [100., 0.]])
+    cases.append(("rot_trans", a, a @ rot2(45).T + [5, 5], rot2(45), [5, 5], TE, RE, None))
+    a = np.array([[0., 0.], [100., 0.], [50., 50.], [0., 50.]])
+    noise = np.fromfile(os.path.join(GOLDEN, "noise2d_f64.bin")).reshape(4, 2)
+    cases.append(("noise", a, a @ rot2(30).T + [20, 10] + noise, rot2(30), [20, 10], TE * 3, RE * 5, None))
+    return cases
+
+
+def reference_cases_3d():
+    """The five cases of tests/test3d.cpp:36-202 as (name, a, b, R, t, trans_eps, rot_eps, max_it)."""
+    TE, RE = 0.5, 0.01
+    cases = []
+    cases.append(("single_point", np.array([[0., 0., 0.]]), np.array([[100., 0., 0.]]), np.eye(3), [100, 0, 0], TE, RE, 10))
+    a = np.eye(3)
+    c = a.mean(axis=0)
+    for deg in range(10):
+        R = rot3_zyx(deg, 0, 0)
+        t = c - R @ c
+        cases.append((f"rotx_{deg}", a, a @ R.T + t, R, t, TE, RE, None))
+    R = rot3_zyx(30, 30, 30)
+    t = c - R @ c
+    cases.append(("rot_multi", a, a @ R.T + t, R, t, TE, RE, None))
+    a = 100.0 * np.eye(3)
+    R = rot3_zyx(10, 10, 10)
+    cases.append(("rot_trans", a, a @ R.T + [50, 50, 50], R, [50, 50, 50], TE, RE, None))
+    noise = np.fromfile(os.path.join(GOLDEN, "noise3d_f64.bin")).reshape(3, 3)
+    cases.append(("noise", a, a @ R.T + [20, 10, 30] + noise, R, [20, 10, 30], TE + 1.0, 0.1, None))
+    return cases
+
+
+def smallest_angle(R):
+    return np.arctan2(R[1, 0], R[0, 0])
+
+
+def is_approx(a, b, eps):
+    """Eigen isApprox: ||a-b|| <= eps * min(||a||, ||b||) (Frobenius)"""
+    return np.linalg.norm(a - b) <= eps * min(np.linalg.norm(a), np.linalg.norm(b))
+
+
+def check_case_2d(T, iters, case):
+    name, a, b, R, t, te, re_, max_it = case
+    assert np.all(np.abs(T[:2, 2] - np.asarray(t, float)) < te), (name, T)
+    assert abs(smallest_angle(T[:2, :2]) - smallest_angle(R)) < re_, (name, T)
+    if max_it is not None:
+        assert iters <= max_it, name
+
+
+def check_case_3d(T, iters, case):
+    name, a, b, R, t, te, re_, max_it = case
+    assert np.all(np.abs(T[:3, 3] - np.asarray(t, float)) < te), (name, T)
+    assert is_approx(T[:3, :3], R, re_), (name, T)
+    if max_it is not None:
+        assert iters <= max_it, name

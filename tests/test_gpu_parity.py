@@ -1,0 +1,423 @@
+"""GPU parity tests: the HIP path, called through the C ABI (icp_amd._lib / icp_amd.api), against
+the CPU oracle on the same inputs.
+
+Bars (tier ③): correspondence indices and squared distances BIT-EXACT against the canonical
+(d2, index) rule; whole converge() runs bit-exact against the oracle in device summation order
+(TREE64) — transforms, costs, iteration counts, matches; and within 1e-6 rad / 1e-6 m (north_star)
+against the oracle in the reference's summation order.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import (BENCH_CRIT, PLY_CRIT, TEST_CRIT, check_case_2d, check_case_3d,
+                      reference_cases_2d, reference_cases_3d)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6  # north_star: 1e-6 rad and 1e-6 m
+
+
+@pytest.fixture(scope="module")
+def icp():
+    import icp_amd
+    icp_amd._lib.check(icp_amd._lib.load().icpx_init(0))
+    return icp_amd
+
+
+def dev_oracle(ob, dim, method, **kw):
+    return ob.OracleICP(dim, method, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64, **kw)
+
+
+def driver(icp, cls, method, crit, config=None, **kw):
+    d = icp.ICPDriver(cls.from_method(method, config, **kw))
+    if "max_iterations" in crit:
+        d.set_max_iterations(crit["max_iterations"])
+    if "min_iterations" in crit:
+        d.set_min_iterations(crit["min_iterations"])
+    if "transform_tol" in crit:
+        d.set_transform_tolerance(*crit["transform_tol"])
+    if "stop_cost" in crit:
+        d.set_stop_cost(crit["stop_cost"])
+    if "absolute" in crit:
+        d.set_absolute_cost_tolerance(crit["absolute"])
+    if "relative" in crit:
+        d.set_relative_cost_tolerance(crit["relative"])
+    return d
+
+
+# ------------------------------------------------------------------------------------------
+# per-call NN parity
+# ------------------------------------------------------------------------------------------
+
+def nn_cases(scans, queen):
+    rng = np.random.default_rng(11)
+    cases = [("scan1", *scans[1]), ("scan2", *scans[2]), ("scan3", *scans[3]), ("queen", *queen)]
+    cases.append(("rand2d", rng.uniform(-10, 10, (3000, 2)), rng.uniform(-10, 10, (2500, 2))))
+    cases.append(("rand3d", rng.uniform(-10, 10, (5000, 3)), rng.uniform(-10, 10, (7001, 3))))
+    # exact ties: integer lattice with many duplicates
+    cases.append(("lattice2d", rng.integers(0, 6, (700, 2)).astype(float), rng.integers(0, 6, (900, 2)).astype(float)))
+    cases.append(("lattice3d", rng.integers(0, 4, (600, 3)).astype(float), rng.integers(0, 4, (1100, 3)).astype(float)))
+    # ragged / tiny
+    cases.append(("one_one", np.array([[1., 2., 3.]]), np.array([[4., 5., 6.]])))
+    cases.append(("one_target", rng.normal(size=(130, 2)), np.array([[0.5, 0.5]])))
+    cases.append(("one_query", np.array([[0.1, 0.2]]), rng.normal(size=(1025, 2))))
+    # queries far outside the target's bounding box, clustered targets, degenerate extents
+    cases.append(("outside", rng.uniform(50, 60, (400, 3)), rng.uniform(-1, 1, (3000, 3))))
+    clus = np.concatenate([rng.normal(c, 0.01, (800, 3)) for c in ([0, 0, 0], [5, 5, 5], [-7, 3, 1])])
+    cases.append(("clustered", rng.uniform(-8, 8, (1500, 3)), clus))
+    line = np.stack([np.linspace(-3, 3, 2000), np.zeros(2000), np.full(2000, 2.0)], axis=1)
+    cases.append(("collinear", rng.uniform(-4, 4, (900, 3)), line))
+    plane = np.concatenate([rng.uniform(-5, 5, (4000, 2)), np.zeros((4000, 1))], axis=1)
+    cases.append(("planar", rng.uniform(-5, 5, (1000, 3)), plane))
+    cases.append(("same_point", rng.normal(size=(64, 2)), np.tile([[1.0, -1.0]], (500, 1))))
+    return cases
+
+
+@pytest.mark.parametrize("mode", ["brute", "grid"])
+def test_nn_bit_exact(icp, ob, scans, queen, mode):
+    m = icp.NN_BRUTE if mode == "brute" else icp.NN_GRID
+    for name, q, t in nn_cases(scans, queen):
+        idx, d2 = icp.nearest_neighbors(q, t, m)
+        oi, od2 = ob.nn_brute(q, t)
+        assert np.array_equal(idx, oi), (name, mode, np.nonzero(idx != oi)[0][:5])
+        assert np.array_equal(d2, od2), (name, mode)
+
+
+def test_nn_empty_and_nonfinite(icp, ob):
+    q = np.array([[0.0, 0.0], [np.nan, 1.0], [np.inf, 0.0], [1.0, 1.0]])
+    t = np.array([[1.0, 1.0], [np.nan, 0.0], [0.25, 0.0], [np.inf, np.inf]])
+    for m in (icp.NN_BRUTE, icp.NN_GRID):
+        idx, d2 = icp.nearest_neighbors(q, t, m)
+        oi, od2 = ob.nn_brute(q, t)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+        idx, d2 = icp.nearest_neighbors(q, np.zeros((0, 2)), m)  # no targets: (0, inf)
+        assert np.all(idx == 0) and np.all(np.isinf(d2))
+        idx, d2 = icp.nearest_neighbors(np.zeros((0, 2)), t, m)
+        assert len(idx) == 0
+
+
+def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen):
+    """Against the REAL reference kd-tree (oracle/_ref when present, else its restatement):
+    indices may differ only where sqrt(d2) is bit-identical; the count is reported."""
+    total = 0
+    for name, (q, t) in [("scan1", scans[1]), ("scan2", scans[2]), ("scan3", scans[3]), ("queen", queen)]:
+        ki, kd = ob.ref_nn_kdtree(q, t) if ob.ref_lib() is not None else ob.nn_kdtree(q, t)
+        idx, d2 = icp.nearest_neighbors(q, t, icp.NN_AUTO)
+        assert np.array_equal(np.sqrt(d2), kd), name
+        diff = np.nonzero(idx != ki)[0]
+        for i in diff:
+            assert np.sqrt(((t[ki[i]] - q[i]) ** 2).sum()) == np.sqrt(d2[i])
+        total += len(diff)
+    print("kd-tree tie picks that differ from the (d2, index) rule:", total)
+
+
+# ------------------------------------------------------------------------------------------
+# whole converge() runs
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("method", ["vanilla", "trimmed"])
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k):
+    a, b = scans[k]
+    d = driver(icp, icp.ICP2, method, BENCH_CRIT)
+    r = d.converge(a, b)
+    o = dev_oracle(ob, 2, method)
+    ro = o.converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
+    assert r.iteration_count == ro.iteration_count
+    assert np.array_equal(r.transform, ro.transform)
+    assert r.cost == ro.cost
+    p, q, c = d.icp_.get_matches_arrays()
+    po, qo, co = o.get_matches()
+    assert np.array_equal(p, po) and np.array_equal(q, qo) and np.array_equal(c, co)
+    # committed golden vectors (device order: exact; reference order: north_star tolerance)
+    g = traces[f"scan{k}/{method}/dev"]
+    assert r.iteration_count == g["iterations"] and np.array_equal(r.transform, g["transform"])
+    gr = traces[f"scan{k}/{method}/ref"]
+    assert r.iteration_count == gr["iterations"]
+    tol = 1e-5 if (k == 1 and method == "vanilla") else TOL  # one kd-tree tie pick (see test_oracle)
+    assert np.abs(r.transform - gr["transform"]).max() < tol
+    # reference summation order with the canonical NN: always within 1e-6
+    rs = ob.OracleICP(2, method, nn_mode=ob.NN_BRUTE).converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
+    assert rs.iteration_count == r.iteration_count
+    assert np.abs(rs.transform - r.transform).max() < TOL
+    assert abs(rs.cost - r.cost) < 1e-12
+
+
+@pytest.mark.parametrize("method", ["vanilla", "trimmed"])
+def test_queen_large_path(icp, ob, queen, traces, method):
+    """BASELINE config 3 (10 720 points): grid NN + multi-kernel reductions."""
+    src, dst = queen
+    d = driver(icp, icp.ICP3, method, PLY_CRIT)
+    r = d.converge(src, dst)
+    g = traces[f"queen/{method}/dev"]
+    assert r.iteration_count == g["iterations"] == 12
+    assert np.array_equal(r.transform, g["transform"])
+    assert np.abs(r.transform - traces[f"queen/{method}/ref"]["transform"]).max() < TOL
+    assert r.cost == 0.0  # Q4
+    p, q, c = d.icp_.get_matches_arrays()
+    assert not p.any() and not q.any() and not c.any()
+    # neighbours of the last iteration against the oracle's
+    o = dev_oracle(ob, 3, method)
+    o.converge(src, dst, None, ob.make_criteria(**PLY_CRIT))
+    oi, od = o.neighbors()
+    idx, dist = d.icp_.debug_neighbors()
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+@pytest.mark.parametrize("dim,method", [(2, "vanilla"), (2, "trimmed"), (3, "vanilla"), (3, "trimmed")])
+def test_stepwise_begin_iterate_matches_oracle_every_iteration(icp, ob, scans, dim, method):
+    if dim == 2:
+        a, b = scans[3]
+        cfg = None
+        okw = {}
+    else:
+        from icp_amd import synth
+        a, b, _, _ = synth.config5_pairs([5], 3, 700)
+        cfg = icp.Config()
+        cfg.set("max_distance", 0.35)
+        okw = {"max_distance": 0.35}
+    cls = icp.ICP2 if dim == 2 else icp.ICP3
+    g = np.eye(dim + 1)
+    g[:dim, dim] = 0.05
+    x = cls.from_method(method, cfg)
+    o = dev_oracle(ob, dim, method, **okw)
+    x.begin(a, b, g)
+    o.begin(a, b, g)
+    assert x.calculate_cost() == o.calculate_cost()
+    assert np.array_equal(x.current_transform(), o.current_transform())
+    for it in range(6):
+        x.iterate()
+        o.iterate()
+        assert np.array_equal(x.current_transform(), o.current_transform()), it
+        assert x.calculate_cost() == o.calculate_cost(), it
+        if dim == 2:
+            for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+                assert np.array_equal(u, v), it
+        else:
+            for u, v in zip(x.debug_neighbors(), o.neighbors()):
+                assert np.array_equal(u, v), it
+
+
+def test_fused_sizes_and_overlap_variants(icp, ob):
+    """Every fused-kernel geometry (queries per lane 1/2/4/8) in 2D and 3D, ragged sizes."""
+    from icp_amd import synth
+    crit = dict(max_iterations=12, transform_tol=(1e-5, 1e-5))
+    for dim, n, m in [(2, 1, 1), (2, 63, 65), (2, 200, 300), (2, 500, 400), (2, 1000, 1024), (2, 2000, 1500),
+                      (2, 4096, 4096), (3, 100, 90), (3, 700, 800), (3, 1500, 1400), (3, 4096, 4096)]:
+        s, t, _, _ = synth.config5_pairs([n + dim], dim, max(n, m))
+        s, t = s[:n], t[:m]
+        for method, ov in (("vanilla", 0.9), ("trimmed", 0.9), ("trimmed", 0.5)):
+            if dim == 3 and ov == 0.5:
+                continue
+            cfg = icp.Config()
+            cfg.set("overlap_rate", ov)
+            cfg.set("max_distance", 0.3)
+            cls = icp.ICP2 if dim == 2 else icp.ICP3
+            r = driver(icp, cls, method, crit, cfg).converge(s, t)
+            ro = dev_oracle(ob, dim, method, overlap_rate=ov, max_distance=0.3).converge(
+                s, t, None, ob.make_criteria(**crit))
+            assert r.iteration_count == ro.iteration_count, (dim, n, m, method, ov)
+            assert np.array_equal(r.transform, ro.transform, equal_nan=True), (dim, n, m, method, ov)
+            assert r.cost == ro.cost or (np.isnan(r.cost) and np.isnan(ro.cost))
+
+
+def test_grid_forced_on_small_clouds_uses_large_path(icp, ob, scans):
+    """nn = grid routes scan-sized clouds through the multi-kernel path: same bits."""
+    a, b = scans[2]
+    cfg = icp.Config()
+    cfg.set("nn", "grid")
+    d = driver(icp, icp.ICP2, "vanilla", BENCH_CRIT, cfg)
+    r = d.converge(a, b)
+    o = dev_oracle(ob, 2, "vanilla")
+    ro = o.converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
+    assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
+    assert r.cost == ro.cost
+    for u, v in zip(d.icp_.get_matches_arrays(), o.get_matches()):
+        assert np.array_equal(u, v)
+    from icp_amd import synth
+    s, t, _, _ = synth.config5_pairs([77], 3, 900)
+    for method in ("vanilla", "trimmed"):
+        cfg = icp.Config()
+        cfg.set("nn", "grid")
+        cfg.set("max_distance", 0.4)
+        crit = dict(max_iterations=15, transform_tol=(1e-6, 1e-6))
+        r = driver(icp, icp.ICP3, method, crit, cfg).converge(s, t)
+        ro = dev_oracle(ob, 3, method, max_distance=0.4).converge(s, t, None, ob.make_criteria(**crit))
+        assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
+
+
+def test_driver_criteria_on_device(icp, ob, scans):
+    a, b = scans[1]
+    for crit in [dict(max_iterations=5), dict(max_iterations=0), dict(min_iterations=7, max_iterations=50, stop_cost=1e9),
+                 dict(max_iterations=50, absolute=1e-3), dict(max_iterations=50, relative=1e-2),
+                 dict(max_iterations=50, stop_cost=0.3), dict(min_iterations=3, max_iterations=3)]:
+        r = driver(icp, icp.ICP2, "trimmed", crit).converge(a, b)
+        ro = dev_oracle(ob, 2, "trimmed").converge(a, b, None, ob.make_criteria(**crit))
+        assert r.iteration_count == ro.iteration_count, crit
+        assert np.array_equal(r.transform, ro.transform), crit
+    # Q4 in 3D: the cost is 0, so absolute tolerance stops after 1 iteration, stop_cost at once
+    from icp_amd import synth
+    s, t, _, _ = synth.config5_pairs([1], 3, 300)
+    assert driver(icp, icp.ICP3, "vanilla", dict(max_iterations=50, absolute=1e-9)).converge(s, t).iteration_count == 1
+    assert driver(icp, icp.ICP3, "vanilla", dict(max_iterations=50, stop_cost=1e-9)).converge(s, t).iteration_count == 0
+    # time limit: generous limit does not stop early; zero limit stops at the first check
+    d = driver(icp, icp.ICP2, "trimmed", BENCH_CRIT)
+    d.set_time_limit(60.0)
+    assert d.converge(a, b).iteration_count == 22
+    d.set_time_limit(0.0)
+    assert d.converge(a, b).iteration_count == 0
+
+
+@pytest.mark.parametrize("method,overlap", [("vanilla", 0.9), ("trimmed", 1.0)])
+def test_reference_2d_cases_through_product_api(icp, method, overlap):
+    """tests/test.cpp:83-216 with the reference's own tolerances."""
+    cfg = icp.Config()
+    cfg.set("overlap_rate", overlap)
+    d = driver(icp, icp.ICP2, method, TEST_CRIT, cfg)
+    for case in reference_cases_2d():
+        r = d.converge(case[1], case[2])
+        check_case_2d(r.transform, r.iteration_count, case)
+
+
+def test_reference_3d_cases_through_product_api(icp):
+    """tests/test3d.cpp:36-202 (Vanilla3d) with the reference's own tolerances."""
+    d = driver(icp, icp.ICP3, "vanilla", TEST_CRIT)
+    for case in reference_cases_3d():
+        r = d.converge(case[1], case[2])
+        check_case_3d(r.transform, r.iteration_count, case)
+
+
+def test_empty_clouds_are_noops(icp):
+    e2, p2 = np.zeros((0, 2)), np.array([[1.0, 2.0], [3.0, 4.0]])
+    for method in ("vanilla", "trimmed"):
+        x = icp.ICP2.from_method(method)
+        x.begin(e2, p2)
+        assert np.isnan(x.calculate_cost())  # sqrt(0/0), icp.h:154
+        x.iterate()
+        assert np.array_equal(x.current_transform(), np.eye(3))
+        x.begin(p2, e2)
+        x.iterate()
+        assert np.array_equal(x.current_transform(), np.eye(3))
+        assert x.calculate_cost() == 0.0
+    r = driver(icp, icp.ICP3, "vanilla", dict(max_iterations=3)).converge(np.zeros((0, 3)), np.zeros((5, 3)))
+    assert r.iteration_count == 3 and np.array_equal(r.transform, np.eye(4))
+
+
+def test_batch_equals_single_pairs(icp, ob):
+    from icp_amd import synth
+    crit = icp.make_criteria(max_iterations=30, transform_tol=(1e-4, 1e-4))
+    for dim, n, method in [(2, 300, "trimmed"), (2, 300, "vanilla"), (3, 500, "vanilla"), (3, 500, "trimmed")]:
+        P = 9
+        s, t, off, _ = synth.config5_pairs(range(100, 100 + P), dim, n)
+        # ragged: drop some points of every pair; pair 4 is empty
+        so, to = [0], [0]
+        ss, tt = [], []
+        for p in range(P):
+            ns = 0 if p == 4 else n - 7 * p
+            nt = n - 3 * p
+            ss.append(s[off[p]:off[p] + ns])
+            tt.append(t[off[p]:off[p] + nt])
+            so.append(so[-1] + ns)
+            to.append(to[-1] + nt)
+        S, T = np.concatenate(ss), np.concatenate(tt)
+        cost, its, Ts = icp.converge_batch(dim, method, S, np.array(so), T, np.array(to), crit)
+        for p in range(P):
+            if len(ss[p]) == 0:
+                # Q10: the reference is UB (2D trimmed) / NaN (3D) on an empty source; the product
+                # defines iterate() as a no-op there — not a parity target
+                assert np.array_equal(Ts[p], np.eye(dim + 1)), (dim, method, p)
+                continue
+            ro = dev_oracle(ob, dim, method).converge(ss[p], tt[p], None,
+                                                      ob.make_criteria(max_iterations=30, transform_tol=(1e-4, 1e-4)))
+            assert its[p] == ro.iteration_count, (dim, method, p)
+            assert np.array_equal(Ts[p], ro.transform), (dim, method, p)
+            assert cost[p] == ro.cost or (np.isnan(cost[p]) and np.isnan(ro.cost))
+
+
+def test_device_resident_inputs_and_outputs(icp, scans):
+    """torch CUDA tensors go into the C ABI as device pointers (no host staging)."""
+    import torch
+    a, b = scans[1]
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    r_host = driver(icp, icp.ICP2, "trimmed", BENCH_CRIT).converge(a, b)
+    r_dev = driver(icp, icp.ICP2, "trimmed", BENCH_CRIT).converge(da, db)
+    assert r_dev.iteration_count == r_host.iteration_count and np.array_equal(r_dev.transform, r_host.transform)
+    out = torch.zeros(18, dtype=torch.float64, device="cuda")
+    crit = icp.make_criteria(**BENCH_CRIT)
+    icp.converge_batch(2, "trimmed", da, np.array([0, len(a)]), db, np.array([0, len(b)]), crit, out_states=out)
+    o = out.cpu().numpy()
+    assert o[0] == r_host.cost and o[1:2].view(np.uint64)[0] == r_host.iteration_count
+    assert np.array_equal(o[2:11].reshape(3, 3, order="F"), r_host.transform)
+    idx = torch.zeros(len(a), dtype=torch.int64, device="cuda")
+    d2 = torch.zeros(len(a), dtype=torch.float64, device="cuda")
+    icp.nearest_neighbors(da, db, icp.NN_BRUTE, out_idx=idx, out_d2=d2)
+    hi, hd = icp.nearest_neighbors(a, b, icp.NN_GRID)
+    assert np.array_equal(idx.cpu().numpy(), hi) and np.array_equal(d2.cpu().numpy(), hd)
+
+
+def test_error_behaviour(icp):
+    L = icp._lib
+    lib = L.load()
+    h = L._vp()
+    assert lib.icpx_create(4, 0, None, C.byref(h)) == L.ERR_INVALID
+    assert b"dim" in lib.icpx_last_error()
+    assert lib.icpx_create(2, 7, None, C.byref(h)) == L.ERR_INVALID
+    assert lib.icpx_create(2, 0, None, C.byref(h)) == L.OK
+    assert lib.icpx_iterate(h) == L.ERR_STATE  # iterate before begin (icp.h:42-43 calls it UB)
+    out = C.c_double()
+    assert lib.icpx_cost(h, C.byref(out)) == L.ERR_STATE
+    a = np.zeros((3, 2))
+    g = np.eye(3)
+    assert lib.icpx_begin(h, None, 3, a.ctypes.data, 3, g.ctypes.data) == L.ERR_INVALID
+    assert lib.icpx_begin(h, a.ctypes.data, -1, a.ctypes.data, 3, g.ctypes.data) == L.ERR_INVALID
+    assert lib.icpx_begin(h, a.ctypes.data, 3, a.ctypes.data, 3, g.ctypes.data) == L.OK
+    assert lib.icpx_iterate(h) == L.OK
+    assert lib.icpx_destroy(h) == L.OK
+    assert lib.icpx_destroy(None) == L.OK
+    assert lib.icpx_iterate(None) == L.ERR_INVALID
+    # trimmed ICP2 beyond the fused limits is not implemented: a clear error, not a wrong answer
+    big = np.random.default_rng(0).normal(size=(5000, 2))
+    x = icp.ICP2.from_method("trimmed")
+    with pytest.raises(icp.IcpxError) as e:
+        x.begin(big, big)
+    assert e.value.code == L.ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE full sizes: size-independent properties
+# ------------------------------------------------------------------------------------------
+
+def test_config4_grid_nn_one_million_points(icp, ob):
+    """1 M x 1 M (BASELINE config 4): (1) self-query is the identity with d2 = 0 (idempotence);
+    (2) 300 sampled queries bit-exact against the oracle's brute force over all 1 M targets;
+    (3) the clustered variant (non-uniform cells) likewise."""
+    from icp_amd import synth
+    for clustered in (False, True):
+        src, tgt, R, t = synth.config4(1_000_000, clustered=clustered)
+        idx, d2 = icp.nearest_neighbors(tgt, tgt, icp.NN_GRID)
+        uniq = len(np.unique(tgt, axis=0)) == len(tgt)
+        assert np.all(d2 == 0.0)
+        if uniq:
+            assert np.array_equal(idx, np.arange(len(tgt)))
+        idx, d2 = icp.nearest_neighbors(src, tgt, icp.NN_GRID)
+        sample = np.random.default_rng(5).choice(len(src), 300, replace=False)
+        oi, od2 = ob.nn_brute(src[sample], tgt)
+        assert np.array_equal(idx[sample], oi) and np.array_equal(d2[sample], od2)
+        assert np.all(d2 >= 0) and np.all(np.isfinite(d2))
+
+
+def test_config4_converge_recovers_known_transform(icp):
+    """Full converge at 1 M points (50 iterations; at this density point-to-point ICP creeps, the
+    oracle does the same at smaller n): re-running is bit-reproducible and the estimate has moved
+    most of the way from the identity guess towards the generator's inverse (R, t)."""
+    from icp_amd import synth
+    src, tgt, R, t = synth.config4(1_000_000)
+    crit = dict(max_iterations=50, transform_tol=(1e-4, 1e-4))
+    r1 = driver(icp, icp.ICP3, "vanilla", crit).converge(src, tgt)
+    r2 = driver(icp, icp.ICP3, "vanilla", crit).converge(src, tgt)
+    assert r1.iteration_count == r2.iteration_count and np.array_equal(r1.transform, r2.transform)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    assert np.abs(r1.transform @ T - np.eye(4)).max() < 0.5 * np.abs(T - np.eye(4)).max()
