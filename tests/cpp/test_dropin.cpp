@@ -294,16 +294,16 @@ void test_interface_semantics() {
     a.col(0) << 0, 0;
     a.col(1) << 1, 0;
     a.col(2) << 0, 2;
-    b.col(0) << 0.5, 0;
-    b.col(1) << 1.5, 0;
-    b.col(2) << 0.5, 2;
+    b.col(0) << 0.25, 0;
+    b.col(1) << 1.25, 0;
+    b.col(2) << 0.25, 2;
     icp->begin(a, b, icp::RBTransform2::Identity());
     double c0 = icp->calculate_cost();
-    assert_true(std::abs(c0 - 0.5) < 1e-12);  // RMS of d2 = 0.25 each
+    assert_true(std::abs(c0 - 0.25) < 1e-12);  // RMS of d2 = 0.0625 each
     icp->iterate();
     icp->iterate();
     assert_true(icp->calculate_cost() < 1e-9);
-    assert_true(std::abs(icp->current_transform().translation().x() - 0.5) < 1e-9);
+    assert_true(std::abs(icp->current_transform().translation().x() - 0.25) < 1e-9);
     assert_true(icp->get_matches().size() == 3);
     // third-party subclass through the driver's host loop
     auto mine = std::make_unique<ShiftToCentroid>();
@@ -312,7 +312,7 @@ void test_interface_semantics() {
     driver.set_max_iterations(3);
     auto r = driver.converge(a, b, icp::RBTransform2::Identity());
     assert_true(r.iteration_count == 3 && raw->setups == 1);
-    assert_true(std::abs(r.transform.translation().x() - 0.5) < 1e-12);
+    assert_true(std::abs(r.transform.translation().x() - 0.25) < 1e-12);
     assert_true(std::abs(r.cost - 0.5) < 1e-12);
 }
 
