@@ -13,6 +13,8 @@
 //           the stream with a device-side done flag (icpx_large.h).
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -108,8 +110,16 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g) {
     else if (n <= 1024) { r.qpt = 2; r.threads = 512; }
     else if (n <= 2048) { r.qpt = 4; r.threads = 512; }
     else { r.qpt = 8; r.threads = 512; }
-    r.tcap = static_cast<int>((m + 1) & ~int64_t(1));
-    if (r.tcap < 2) r.tcap = 2;
+    // development override: ICPX_GEOM="qpt,threads" (must cover n)
+    if (const char* e = std::getenv("ICPX_GEOM")) {
+        int q = 0, t = 0;
+        if (std::sscanf(e, "%d,%d", &q, &t) == 2 && static_cast<int64_t>(q) * t >= n) {
+            r.qpt = q;
+            r.threads = t;
+        }
+    }
+    r.tcap = static_cast<int>((m + 3) & ~int64_t(3));  // targets are consumed four at a time
+    if (r.tcap < 4) r.tcap = 4;
     r.scap = (dim == 2 && method == ICPX_TRIMMED) ? next_pow2(static_cast<int>(n)) : 0;
     r.lds = pair_lds_bytes(dim, r.tcap, r.scap);
     if (r.lds > kMaxLds) return false;
@@ -140,11 +150,19 @@ int launch_one(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStrea
 
 template <int D, int METHOD>
 int launch_dm(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
-    if (g.qpt == 1) return launch_one<D, METHOD, 1, 256>(pb, n_pairs, g, stream);
-    if (g.qpt == 2 && g.threads == 256) return launch_one<D, METHOD, 2, 256>(pb, n_pairs, g, stream);
-    if (g.qpt == 2) return launch_one<D, METHOD, 2, 512>(pb, n_pairs, g, stream);
-    if (g.qpt == 4) return launch_one<D, METHOD, 4, 512>(pb, n_pairs, g, stream);
-    return launch_one<D, METHOD, 8, 512>(pb, n_pairs, g, stream);
+    const int key = g.qpt * 10000 + g.threads;
+    switch (key) {
+        case 10256: return launch_one<D, METHOD, 1, 256>(pb, n_pairs, g, stream);
+        case 20256: return launch_one<D, METHOD, 2, 256>(pb, n_pairs, g, stream);
+        case 40256: return launch_one<D, METHOD, 4, 256>(pb, n_pairs, g, stream);
+        case 80256: return launch_one<D, METHOD, 8, 256>(pb, n_pairs, g, stream);
+        case 160256: return launch_one<D, METHOD, 16, 256>(pb, n_pairs, g, stream);
+        case 20512: return launch_one<D, METHOD, 2, 512>(pb, n_pairs, g, stream);
+        case 40512: return launch_one<D, METHOD, 4, 512>(pb, n_pairs, g, stream);
+        case 80512: return launch_one<D, METHOD, 8, 512>(pb, n_pairs, g, stream);
+        case 41024: return launch_one<D, METHOD, 4, 1024>(pb, n_pairs, g, stream);
+        default: return fail(ICPX_ERR_INVALID, "no fused kernel for %d queries per lane x %d threads", g.qpt, g.threads);
+    }
 }
 
 int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {

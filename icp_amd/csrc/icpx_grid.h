@@ -71,6 +71,8 @@ __global__ void grid_bbox_kernel(const double* __restrict__ t, int64_t m, unsign
             }
         }
     }
+    __shared__ unsigned long long smn[D][16], smx[D][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
 #pragma unroll
     for (int d = 0; d < D; d++) {
 #pragma unroll
@@ -80,10 +82,21 @@ __global__ void grid_bbox_kernel(const double* __restrict__ t, int64_t m, unsign
             o = __shfl_xor(mx[d], s, 64);
             mx[d] = o > mx[d] ? o : mx[d];
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&keys[d], mn[d]);
-            atomicMax(&keys[3 + d], mx[d]);
+        if (lane == 0) {
+            smn[d][wave] = mn[d];
+            smx[d][wave] = mx[d];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        unsigned long long a = smn[d][0], b = smx[d][0];
+        for (int w = 1; w < W; w++) {
+            a = smn[d][w] < a ? smn[d][w] : a;
+            b = smx[d][w] > b ? smx[d][w] : b;
+        }
+        atomicMin(&keys[d], a);
+        atomicMax(&keys[3 + d], b);
     }
 }
 
@@ -104,7 +117,7 @@ ICPX_DEV int cell_of(const GridParams& gp, const double* p) {
 
 template <int D>
 __global__ void grid_count_kernel(const double* __restrict__ t, GridParams gp, int* __restrict__ cell_id,
-                                  int* __restrict__ counts) {
+                                  int* __restrict__ counts, int* __restrict__ occupied) {
     int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= gp.m) return;
     double p[D];
@@ -112,22 +125,39 @@ __global__ void grid_count_kernel(const double* __restrict__ t, GridParams gp, i
     for (int d = 0; d < D; d++) p[d] = t[j * D + d];
     int c = cell_of<D>(gp, p);
     cell_id[j] = c;
-    atomicAdd(&counts[c], 1);
+    if (atomicAdd(&counts[c], 1) == 0) atomicAdd(occupied, 1);
 }
 
-// exclusive scan of counts[0..ncell) into start[0..ncell], start[ncell] = total.  One block.
-__global__ void __launch_bounds__(1024) grid_scan_kernel(const int* __restrict__ counts, int ncell,
-                                                          int* __restrict__ start) {
+// exclusive scan of counts[0..ncell) into start[0..ncell] (start[ncell] = total) in three steps:
+// per-block totals (kScanBlk cells per block), one-block scan of the totals, per-block local scan.
+constexpr int kScanBlk = 4096;
+
+__global__ void __launch_bounds__(256) grid_scan_totals_kernel(const int* __restrict__ counts, int ncell,
+                                                                int* __restrict__ totals) {
+    __shared__ int ws[4];
+    const int base = blockIdx.x * kScanBlk;
+    int s = 0;
+    for (int i = threadIdx.x; i < kScanBlk; i += 256) {
+        int c = base + i;
+        s += c < ncell ? counts[c] : 0;
+    }
+    s = wave_sum_int(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) totals[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// in-place exclusive scan of totals[0..nb); totals[nb] = grand total.  One block of 1024.
+__global__ void __launch_bounds__(1024) grid_scan_top_kernel(int* __restrict__ totals, int nb) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
-    const int chunk = (ncell + 1023) / 1024;
+    const int chunk = (nb + 1023) / 1024;
     const int b = tid * chunk;
-    const int e = b + chunk < ncell ? b + chunk : ncell;
+    const int e = b + chunk < nb ? b + chunk : nb;
     int s = 0;
-    for (int i = b; i < e; i++) s += counts[i];
+    for (int i = b; i < e; i++) s += totals[i];
     part[tid] = s;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
     for (int off = 1; off < 1024; off <<= 1) {
         int v = tid >= off ? part[tid - off] : 0;
         __syncthreads();
@@ -136,10 +166,44 @@ __global__ void __launch_bounds__(1024) grid_scan_kernel(const int* __restrict__
     }
     int run = tid == 0 ? 0 : part[tid - 1];
     for (int i = b; i < e; i++) {
-        start[i] = run;
-        run += counts[i];
+        int c = totals[i];
+        totals[i] = run;
+        run += c;
     }
-    if (tid == 1023) start[ncell] = part[1023];
+    if (tid == 1023) totals[nb] = part[1023];
+}
+
+__global__ void __launch_bounds__(256) grid_scan_local_kernel(const int* __restrict__ counts, int ncell,
+                                                               const int* __restrict__ totals,
+                                                               int* __restrict__ start) {
+    __shared__ int part[256];
+    constexpr int PER = kScanBlk / 256;  // consecutive cells per thread
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * kScanBlk + tid * PER;
+    int v[PER];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        int c = base + i;
+        v[i] = c < ncell ? counts[c] : 0;
+        s += v[i];
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int x = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    int run = totals[blockIdx.x] + (tid == 0 ? 0 : part[tid - 1]);
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        int c = base + i;
+        if (c < ncell) start[c] = run;
+        run += v[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) start[ncell] = totals[gridDim.x];
 }
 
 template <int D>
@@ -211,21 +275,31 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                         }
                     }
                     for (int s = 0; s < nseg; s++) {
-                        for (int k = seg_b[s]; k < seg_e[s]; k++) {
-                            GridRec rec = recs[k];
-                            double df = rec.x - q[0];
-                            double dist = df * df;
-                            df = rec.y - q[1];
-                            dist = dist + df * df;
-                            if (D == 3) {
-                                df = rec.z - q[2];
-                                dist = dist + df * df;
+                        // 4 records in flight per step: the walk is latency-bound, not bandwidth-bound
+                        for (int k0 = seg_b[s]; k0 < seg_e[s]; k0 += 4) {
+                            GridRec rec[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                int k = k0 + u < seg_e[s] ? k0 + u : seg_e[s] - 1;
+                                rec[u] = recs[k];
                             }
-                            int j = static_cast<int>(rec.idx);
-                            bool take = dist < best || (dist == best && j < bidx && bidx != 0x7fffffff);
-                            best = take ? dist : best;
-                            bidx = take ? j : bidx;
-                            visited++;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                double df = rec[u].x - q[0];
+                                double dist = df * df;
+                                df = rec[u].y - q[1];
+                                dist = dist + df * df;
+                                if (D == 3) {
+                                    df = rec[u].z - q[2];
+                                    dist = dist + df * df;
+                                }
+                                int j = static_cast<int>(rec[u].idx);
+                                bool take = (k0 + u < seg_e[s]) &&
+                                            (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
+                                best = take ? dist : best;
+                                bidx = take ? j : bidx;
+                            }
+                            visited += seg_e[s] - k0 < 4 ? seg_e[s] - k0 : 4;
                         }
                     }
                 }

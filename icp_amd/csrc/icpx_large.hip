@@ -32,7 +32,7 @@ struct GridIndex {
     GridParams gp{};
     int dim = 0;
     int ncell = 0;
-    DevBuf recs, start, cell_id, counts, keys;
+    DevBuf recs, start, cell_id, counts, keys, totals;
 };
 
 struct LargeDev {
@@ -369,7 +369,7 @@ int grid_create(GridIndex** out) {
 
 void grid_destroy(GridIndex* g) {
     if (!g) return;
-    for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys}) b->release();
+    for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys, &g->totals}) b->release();
     delete g;
 }
 
@@ -394,7 +394,7 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
     ICPX_TRY(g->keys.reserve(sizeof(unsigned long long) * 6));
     unsigned long long init[6] = {~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
     ICPX_HIP(hipMemcpyAsync(g->keys.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    int blocks = static_cast<int>(std::min<int64_t>((m + 255) / 256, 2048));
+    int blocks = static_cast<int>(std::min<int64_t>((m + 255) / 256, 512));
     if (dim == 2)
         hipLaunchKernelGGL(grid_bbox_kernel<2>, dim3(blocks), dim3(256), 0, stream, d_t, m, g->keys.as<unsigned long long>());
     else
@@ -425,42 +425,62 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
         h = std::pow(vol / target_cells, 1.0 / nz);
         if (!(h > 0.0) || !std::isfinite(h)) h = 1.0;
     }
-    const int64_t max_cells = std::min<int64_t>(4 * m + 64, int64_t(1) << 27);
-    for (int attempt = 0; attempt < 64; attempt++) {
-        int64_t total = 1;
-        for (int d = 0; d < dim; d++) {
-            double cnt = ext[d] > 0.0 ? std::floor(ext[d] / h) + 1.0 : 1.0;
-            if (cnt > 2.0e6) cnt = 2.0e6;
-            gp.g[d] = static_cast<int>(cnt);
-            total *= gp.g[d];
-        }
-        if (total <= max_cells) break;
-        h *= 1.26;  // ~ 2^(1/3): halve the cell count per retry in 3D
-    }
-    int64_t total = 1;
-    for (int d = 0; d < dim; d++) {
-        gp.h[d] = h;
-        gp.inv_h[d] = 1.0 / h;
-        total *= gp.g[d];
-    }
-    if (total > max_cells) return fail(ICPX_ERR_UNSUPPORTED, "grid: degenerate cloud extents");
-    gp.rmax = std::max(gp.g[0], std::max(gp.g[1], gp.g[2])) - 1;
-    g->ncell = static_cast<int>(total);
-    // 3. counting sort by cell
+    const int64_t max_cells = std::min<int64_t>(16 * m + 64, int64_t(1) << 26);
     ICPX_TRY(g->cell_id.reserve(sizeof(int) * m));
-    ICPX_TRY(g->counts.reserve(sizeof(int) * (total + 1)));
-    ICPX_TRY(g->start.reserve(sizeof(int) * (total + 1)));
     ICPX_TRY(g->recs.reserve(sizeof(GridRec) * m));
-    ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 1), stream));
-    unsigned mb = static_cast<unsigned>((m + 255) / 256);
-    if (dim == 2)
-        hipLaunchKernelGGL(grid_count_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
-    else
-        hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
+    const unsigned mb = static_cast<unsigned>((m + 255) / 256);
+    int64_t total = 1;
+    // 3. count per cell; surfaces and clusters leave most cells empty, so the edge is halved while
+    //    the OCCUPIED cells hold more than ~6 targets on average and the cell budget allows
+    for (int refine = 0; refine < 5; refine++) {
+        for (int attempt = 0; attempt < 64; attempt++) {
+            total = 1;
+            for (int d = 0; d < dim; d++) {
+                double cnt = ext[d] > 0.0 ? std::floor(ext[d] / h) + 1.0 : 1.0;
+                if (cnt > 2.0e6) cnt = 2.0e6;
+                gp.g[d] = static_cast<int>(cnt);
+                total *= gp.g[d];
+            }
+            if (total <= max_cells) break;
+            h *= 1.26;  // ~ 2^(1/3): halve the cell count per retry in 3D
+        }
+        if (total > max_cells) return fail(ICPX_ERR_UNSUPPORTED, "grid: degenerate cloud extents");
+        for (int d = 0; d < dim; d++) {
+            gp.h[d] = h;
+            gp.inv_h[d] = 1.0 / h;
+        }
+        gp.rmax = std::max(gp.g[0], std::max(gp.g[1], gp.g[2])) - 1;
+        g->ncell = static_cast<int>(total);
+        ICPX_TRY(g->counts.reserve(sizeof(int) * (total + 2)));
+        ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 2), stream));
+        int* d_occ = g->counts.as<int>() + total + 1;
+        if (dim == 2)
+            hipLaunchKernelGGL(grid_count_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>(), d_occ);
+        else
+            hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>(), d_occ);
+        ICPX_HIP(hipGetLastError());
+        if (nz == 0) break;
+        int occ = 0;
+        ICPX_HIP(hipMemcpyAsync(&occ, d_occ, sizeof(int), hipMemcpyDeviceToHost, stream));
+        ICPX_HIP(hipStreamSynchronize(stream));
+        if (occ <= 0 || static_cast<double>(m) / occ <= 6.0) break;
+        // would the halved grid still fit?
+        double next_total = 1.0;
+        for (int d = 0; d < dim; d++) next_total *= ext[d] > 0.0 ? std::floor(ext[d] / (0.5 * h)) + 1.0 : 1.0;
+        if (next_total > static_cast<double>(max_cells)) break;
+        h *= 0.5;
+    }
+    // 4. exclusive scan -> cell starts, then scatter into cell order
+    ICPX_TRY(g->start.reserve(sizeof(int) * (total + 1)));
+    const int nb = static_cast<int>((total + kScanBlk - 1) / kScanBlk);
+    ICPX_TRY(g->totals.reserve(sizeof(int) * (nb + 1)));
+    hipLaunchKernelGGL(grid_scan_totals_kernel, dim3(nb), dim3(256), 0, stream, g->counts.as<int>(), g->ncell, g->totals.as<int>());
     ICPX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, stream, g->counts.as<int>(), g->ncell, g->start.as<int>());
+    hipLaunchKernelGGL(grid_scan_top_kernel, dim3(1), dim3(1024), 0, stream, g->totals.as<int>(), nb);
     ICPX_HIP(hipGetLastError());
-    ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 1), stream));  // reuse as cursors
+    hipLaunchKernelGGL(grid_scan_local_kernel, dim3(nb), dim3(256), 0, stream, g->counts.as<int>(), g->ncell, g->totals.as<int>(), g->start.as<int>());
+    ICPX_HIP(hipGetLastError());
+    ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 2), stream));  // reuse as cursors
     if (dim == 2)
         hipLaunchKernelGGL(grid_scatter_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, m, g->cell_id.as<int>(),
                            g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>());

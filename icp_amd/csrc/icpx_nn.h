@@ -27,42 +27,73 @@ nn_brute_kernel(const double* __restrict__ q, int64_t n, const double* __restric
 
     double qq[kNnQpt][D];
     double best[kNnQpt];
-    int bidx[kNnQpt];
+    int bidx[kNnQpt], bblk[kNnQpt];
 #pragma unroll
     for (int k = 0; k < kNnQpt; k++) {
         int64_t i = qbase + tid + k * kNnThreads;
         best[k] = __builtin_inf();
         bidx[k] = 0;
+        bblk[k] = 0;
 #pragma unroll
         for (int d = 0; d < D; d++) qq[k][d] = i < n ? q[i * D + d] : 0.0;
     }
     for (int64_t base = t0; base < t1; base += kNnTile) {
         const int cnt = static_cast<int>(t1 - base < kNnTile ? t1 - base : kNnTile);
+        const int cnt4 = (cnt + 3) & ~3;
         __syncthreads();
-        for (int j = tid; j < cnt; j += kNnThreads) {
+        for (int j = tid; j < cnt4; j += kNnThreads) {
 #pragma unroll
-            for (int d = 0; d < D; d++) tile[d][j] = t[(base + j) * D + d];
+            for (int d = 0; d < D; d++) tile[d][j] = j < cnt ? t[(base + j) * D + d] : __builtin_inf();
         }
         __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < cnt; j++) {
-            double tc[D];
+        // four targets at a time: block minimum vs running best (see nn_lds in icpx_pair.h)
+        for (int jb = 0; jb < cnt4; jb += 4) {
+            double tc[D][4];
 #pragma unroll
-            for (int d = 0; d < D; d++) tc[d] = tile[d][j];
+            for (int d = 0; d < D; d++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) tc[d][u] = tile[d][jb + u];
 #pragma unroll
             for (int k = 0; k < kNnQpt; k++) {
-                double df = tc[0] - qq[k][0];
-                double dist = df * df;
+                double dist[4];
 #pragma unroll
-                for (int d = 1; d < D; d++) {
-                    df = tc[d] - qq[k][d];
-                    dist = dist + df * df;
+                for (int u = 0; u < 4; u++) {
+                    double df = tc[0][u] - qq[k][0];
+                    double acc = df * df;
+#pragma unroll
+                    for (int d = 1; d < D; d++) {
+                        df = tc[d][u] - qq[k][d];
+                        acc = acc + df * df;
+                    }
+                    dist[u] = acc;
                 }
-                bool lt = dist < best[k];
-                best[k] = lt ? dist : best[k];
-                bidx[k] = lt ? static_cast<int>(base + j) : bidx[k];
+                double mm = __builtin_fmin(__builtin_fmin(dist[0], dist[1]), __builtin_fmin(dist[2], dist[3]));
+                bool lt = mm < best[k];
+                best[k] = __builtin_fmin(best[k], mm);
+                bblk[k] = lt ? static_cast<int>(base - t0) + jb : bblk[k];
             }
         }
+    }
+    // resolve the index inside the winning block of four (lowest j that equals the minimum)
+#pragma unroll
+    for (int k = 0; k < kNnQpt; k++) {
+        int idx = 0;
+        if (best[k] < __builtin_inf()) {
+            for (int u = 3; u >= 0; u--) {
+                int64_t j = t0 + bblk[k] + u;
+                if (j < t1) {
+                    double df = t[j * D + 0] - qq[k][0];
+                    double acc = df * df;
+#pragma unroll
+                    for (int d = 1; d < D; d++) {
+                        df = t[j * D + d] - qq[k][d];
+                        acc = acc + df * df;
+                    }
+                    idx = acc == best[k] ? static_cast<int>(j) : idx;
+                }
+            }
+        }
+        bidx[k] = idx;
     }
 #pragma unroll
     for (int k = 0; k < kNnQpt; k++) {

@@ -85,32 +85,66 @@ inline size_t pair_lds_bytes(int dim, int tcap, int scap) {
 // brute-force NN of QPT register-resident queries against the LDS target cloud.
 // d2 = ((dx*dx) + dy*dy) + dz*dz with dx = target - query (trimmed.cpp:101), strict <,
 // ascending j  =>  lexicographic min of (d2, j).
+//
+// Targets are taken four at a time: the block minimum (v_min_f64 tree) is compared with the
+// running best by strict <, so `bblk` ends as the FIRST block that attains the global minimum —
+// exactly the block the one-by-one loop of the reference would have stopped improving in.  The
+// index inside that block is resolved afterwards by recomputing its four distances (same
+// operations, same bits) and taking the lowest j that equals the minimum.  This costs 9.5 (3D) /
+// 6.5 (2D) VALU instructions per pair instead of 12 / 9 with a per-target compare-and-select.
+// `m4` is m rounded up to a multiple of 4; LDS slots [m, m4) hold +inf (never selected).
 template <int D, int QPT>
-ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m, double (&best)[QPT],
+ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, double (&best)[QPT],
                      int (&bidx)[QPT]) {
+    int bblk[QPT];
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
         best[k] = __builtin_inf();
-        bidx[k] = 0;
+        bblk[k] = 0;
     }
-#pragma unroll 4
-    for (int j = 0; j < m; j++) {
-        double tc[D];
+    for (int jb = 0; jb < m4; jb += 4) {
+        double tc[D][4];
 #pragma unroll
-        for (int d = 0; d < D; d++) tc[d] = L.t[d][j];
+        for (int d = 0; d < D; d++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) tc[d][u] = L.t[d][jb + u];
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
-            double df = tc[0] - q[k][0];
-            double dist = df * df;
+            double dist[4];
 #pragma unroll
-            for (int d = 1; d < D; d++) {
-                df = tc[d] - q[k][d];
-                dist = dist + df * df;
+            for (int u = 0; u < 4; u++) {
+                double df = tc[0][u] - q[k][0];
+                double acc = df * df;
+#pragma unroll
+                for (int d = 1; d < D; d++) {
+                    df = tc[d][u] - q[k][d];
+                    acc = acc + df * df;
+                }
+                dist[u] = acc;
             }
-            bool lt = dist < best[k];
-            best[k] = lt ? dist : best[k];
-            bidx[k] = lt ? j : bidx[k];
+            double mm = __builtin_fmin(__builtin_fmin(dist[0], dist[1]), __builtin_fmin(dist[2], dist[3]));
+            bool lt = mm < best[k];
+            best[k] = __builtin_fmin(best[k], mm);
+            bblk[k] = lt ? jb : bblk[k];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        int idx = 0;
+        if (best[k] < __builtin_inf()) {
+#pragma unroll
+            for (int u = 3; u >= 0; u--) {
+                double df = L.t[0][bblk[k] + u] - q[k][0];
+                double acc = df * df;
+#pragma unroll
+                for (int d = 1; d < D; d++) {
+                    df = L.t[d][bblk[k] + u] - q[k][d];
+                    acc = acc + df * df;
+                }
+                idx = acc == best[k] ? bblk[k] + u : idx;
+            }
+        }
+        bidx[k] = idx;
     }
 }
 
@@ -205,9 +239,10 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
     const bool empty = (n == 0 || m == 0);
 
     // ---- stage the target cloud into LDS as SoA ----
-    for (int j = tid; j < m; j += T) {
+    const int m4 = (m + 3) & ~3;
+    for (int j = tid; j < m4; j += T) {
 #pragma unroll
-        for (int d = 0; d < D; d++) L.t[d][j] = dst[static_cast<int64_t>(j) * D + d];
+        for (int d = 0; d < D; d++) L.t[d][j] = j < m ? dst[static_cast<int64_t>(j) * D + d] : __builtin_inf();
     }
 
     // ---- per-thread point slots ----
@@ -276,7 +311,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            nn_lds<D, QPT>(q, L, m, best, pair);
+            nn_lds<D, QPT>(q, L, m4, best, pair);
 #pragma unroll
             for (int k = 0; k < QPT; k++) {
                 if (METHOD == ICPX_VANILLA) cost[k] = __builtin_sqrt(__builtin_sqrt(best[k]));  // vanilla.cpp:84 on kdtree.h:126
@@ -342,7 +377,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
-                    nn_lds<D, QPT>(cur, L, m, best, pair);
+                    nn_lds<D, QPT>(cur, L, m4, best, pair);
 #pragma unroll
                     for (int k = 0; k < QPT; k++) cost[k] = valid[k] ? best[k] : 0.0;
                     // trimming step, trimmed.cpp:55-58: order by (cost, point), keep the first new_n
@@ -381,7 +416,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 double best[QPT];
-                nn_lds<D, QPT>(cur, L, m, best, pair);
+                nn_lds<D, QPT>(cur, L, m4, best, pair);
 #pragma unroll
                 for (int k = 0; k < QPT; k++) {
                     cost[k] = __builtin_sqrt(__builtin_sqrt(best[k]));  // vanilla_3d.cpp:41 on kdtree.h:126
