@@ -35,7 +35,7 @@ std::string& last_error_ref() {
 
 namespace {
 
-constexpr size_t kMaxLds = 160 * 1024;
+constexpr size_t kMaxLds = 160 * 1024 - 256;  // dynamic LDS budget (the kernel keeps a few static words)
 
 struct DeviceInfo {
     bool ok = false;
@@ -128,7 +128,7 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g) {
 }
 
 template <int D, int METHOD, int QPT, int TMAX>
-int launch_one(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
+int launch_one(const PairBatch& pb_in, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
     auto kern = pair_kernel<D, METHOD, QPT, TMAX>;
     static std::mutex mu;
     static std::unordered_map<int, bool> attr_set;  // per device
@@ -143,7 +143,31 @@ int launch_one(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStrea
             attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_pairs)), dim3(g.threads), g.lds, stream, pb);
+    PairBatch pb = pb_in;
+    int64_t blocks = n_pairs;
+    if (pb.sched_state) {
+        // iteration-granular scheduling pays when the pairs outnumber the resident workgroups only
+        // by a small factor (the tail of a pair-per-workgroup launch is then a large share)
+        DeviceInfo* di = nullptr;
+        ICPX_TRY(device_info(dev, &di));
+        int per_cu = 0;
+        ICPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, g.threads, g.lds));
+        const int64_t resident = static_cast<int64_t>(per_cu > 0 ? per_cu : 1) * di->cus;
+        const char* force = std::getenv("ICPX_SCHED");  // development override: 0 = never, 1 = always
+        bool use = n_pairs > resident && n_pairs <= 16 * resident && n_pairs < (1 << 20) &&
+                   !(D == 2 && METHOD == ICPX_VANILLA);
+        if (force) use = force[0] == '1' && n_pairs < (1 << 20) && !(D == 2 && METHOD == ICPX_VANILLA);
+        if (use) {
+            blocks = n_pairs < resident ? n_pairs : resident;
+            pb.n_pairs = static_cast<int32_t>(n_pairs);
+            pb.sched_steps = 1;
+            ICPX_HIP(hipMemsetAsync(pb.sched_state, 0, sizeof(int32_t) * (n_pairs + 1), stream));
+            pb.sched_done = pb.sched_state + n_pairs;
+        } else {
+            pb.sched_state = nullptr;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(g.threads), g.lds, stream, pb);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -186,7 +210,7 @@ icpx_criteria no_criteria() {
 // per-device grow-only workspace for the handle-free entry points
 struct Workspace {
     std::mutex mu;
-    DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2;
+    DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur;
 };
 Workspace& workspace(int device) {
     static std::mutex mu;
@@ -589,6 +613,14 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
     pb.do_setup = 1;
     pb.check = 1;
     pb.max_steps = UINT64_MAX;
+    // scheduler words (launch_one decides whether to use them) and, for 3D, the running clouds
+    // that a pair carries from one workgroup to the next
+    ICPX_TRY(ws.sched.reserve(sizeof(int32_t) * (n_pairs + 1)));
+    pb.sched_state = ws.sched.as<int32_t>();
+    if (dim == 3) {
+        ICPX_TRY(ws.cur.reserve(sizeof(double) * 3 * (n_total > 0 ? n_total : 1)));
+        pb.cur = ws.cur.as<double>();
+    }
     pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ICPX_TRY(launch_pairs(pb, n_pairs, geom, stream));
     if (!out_on_device) {

@@ -48,6 +48,12 @@ struct PairBatch {
     int32_t check;             // evaluate should_terminate (converge) or not (iterate)
     int32_t lds_target_cap;    // padded target capacity the launch reserved in LDS
     int32_t lds_sort_cap;      // npad reserved for the sort area (2D trimmed)
+    // iteration-granular scheduling (batches whose pairs outnumber the resident workgroups only
+    // slightly): workgroups are persistent and pick (pair, next `sched_steps` iterations) tasks
+    int32_t* sched_state;      // n_pairs words: (iterations done << 2) | {0 fresh, 1 ready, 2 running, 3 done}; null = off
+    int32_t* sched_done;       // number of pairs in state 3
+    int32_t n_pairs;
+    int32_t sched_steps;       // iterations per task
 };
 
 template <int D>
@@ -221,12 +227,13 @@ ICPX_DEV void bitonic_sort(uint64_t* key, uint32_t* val, int npad, int T) {
     }
 }
 
-template <int D, int METHOD, int QPT, int TMAX>
-__global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+// One visit of pair p: optional begin()/setup(), then up to max_steps iterations of the converge
+// loop.  Returns 1 when should_terminate fired (pair finished), 2 when it paused at max_steps.
+template <int D, int METHOD, int QPT>
+ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps,
+                       double* lds_raw) {
     constexpr int L1 = D + 1;
     constexpr int XN = L1 * L1;
-    const int p = blockIdx.x;
     const int T = blockDim.x;
     const int tid = threadIdx.x;
     const int64_t s0 = pb.src_off[p], d0 = pb.dst_off[p];
@@ -260,7 +267,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
         for (int d = 0; d < D; d++) {
             double v = 0.0;
             if (valid[k]) {
-                if (D == 3 && !pb.do_setup) v = pb.cur[(s0 + i) * D + d];
+                if (D == 3 && !do_setup) v = pb.cur[(s0 + i) * D + d];
                 else v = src[static_cast<int64_t>(i) * D + d];
             }
             a[k][d] = v;
@@ -269,7 +276,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
 
     // ---- state ----
     if (tid == 0) {
-        if (pb.do_setup) {
+        if (do_setup) {
             // ICP::begin, icp.h:120-133
             for (int e = 0; e < XN; e++) {
                 double g = pb.guesses ? pb.guesses[static_cast<int64_t>(p) * XN + e]
@@ -295,7 +302,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
     for (int e = 0; e < XN; e++) X.m[e] = L.bc[e];
 
     double state_cost = 0.0;
-    if (pb.do_setup) {
+    if (do_setup) {
         // ---- method setup(): initial matches (2D) ----
         if (D == 2 && !empty) {
             double q[QPT][D];
@@ -340,6 +347,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
 
     // ---- ICPDriver::converge loop, driver.h:63-69 ----
     uint64_t steps = 0;
+    int exit_code = 0;
     while (true) {
         if (tid == 0) {
             int stop = 0;
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
                     st->done = 1;
                 }
             }
-            if (!stop && steps >= pb.max_steps) stop = 2;
+            if (!stop && steps >= max_steps) stop = 2;
             if (!stop) {
                 // last_state = state
                 for (int e = 0; e < XN; e++) st->last_transform[e] = st->transform[e];
@@ -363,6 +371,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
         __syncthreads();
         int stop = reinterpret_cast<int*>(L.bc + 40)[0];
         __syncthreads();
+        exit_code = stop;
         if (stop) break;
         steps++;
 
@@ -543,6 +552,75 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
         o->cost = st->cost;
         o->iteration_count = st->iteration_count;
         for (int e = 0; e < 16; e++) o->transform[e] = e < XN ? st->transform[e] : 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's stores are out before the hand-off
+    __syncthreads();                                   // and LDS may be restaged by the next task
+    return exit_code;
+}
+
+template <int D, int METHOD, int QPT, int TMAX>
+__global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    if (pb.sched_state == nullptr) {
+        pair_body<D, METHOD, QPT>(pb, blockIdx.x, pb.do_setup, pb.max_steps, lds_raw);
+        return;
+    }
+    // ---- persistent workgroup: iteration-granular tasks ----
+    // Hand-off of a pair between workgroups (possibly on different XCDs) follows the agent-scope
+    // release / acquire recipe: every wave drains its stores and meets at the barrier (end of
+    // pair_body), lane 0 releases, then publishes the state word; the taker wins the word with a
+    // CAS, acquires, and only then lets the workgroup load.
+    __shared__ int s_key, s_pick;
+    const int tid = threadIdx.x;
+    const int P = pb.n_pairs;
+    for (int guard = 0; guard < (1 << 30); guard++) {
+        if (tid == 0) s_key = 0x7fffffff;
+        __syncthreads();
+        int best = 0x7fffffff;
+        for (int q = tid; q < P; q += blockDim.x) {
+            int w = __hip_atomic_load(&pb.sched_state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int st = w & 3;
+            if (st <= 1) {
+                // fewest iterations first (longest expected remaining chain), then lowest pair
+                int it = w >> 2;
+                int key = ((it < 2047 ? it : 2047) << 20) | q;
+                best = key < best ? key : best;
+            }
+        }
+        if (best != 0x7fffffff) atomicMin(&s_key, best);
+        __syncthreads();
+        if (tid == 0) {
+            int pick = -2;  // retry
+            if (s_key != 0x7fffffff) {
+                int q = s_key & 0xfffff;
+                int w = __hip_atomic_load(&pb.sched_state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((w & 3) <= 1 && atomicCAS(&pb.sched_state[q], w, (w & ~3) | 2) == w) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pick = (q << 1) | ((w & 3) == 0 ? 1 : 0);  // bit 0: fresh -> run setup
+                }
+            } else if (__hip_atomic_load(pb.sched_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P) {
+                pick = -1;  // everything finished
+            } else {
+                __builtin_amdgcn_s_sleep(64);
+            }
+            s_pick = pick;
+        }
+        __syncthreads();
+        const int pick = s_pick;
+        if (pick == -1) break;
+        if (pick == -2) continue;
+        const int q = pick >> 1;
+        const int code = pair_body<D, METHOD, QPT>(pb, q, pick & 1, static_cast<uint64_t>(pb.sched_steps), lds_raw);
+        // pair_body ended with a barrier behind every wave's stores
+        if (tid == 0) {
+            const int iters = static_cast<int>(pb.states[q].iteration_count);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&pb.sched_state[q], (iters << 2) | (code == 1 ? 3 : 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (code == 1) atomicAdd(pb.sched_done, 1);
+        }
     }
 }
 

@@ -336,6 +336,24 @@ def test_batch_equals_single_pairs(icp, ob):
             assert cost[p] == ro.cost or (np.isnan(cost[p]) and np.isnan(ro.cost))
 
 
+def test_batch_iteration_granular_scheduler_is_bit_identical(icp, monkeypatch):
+    """Batches whose pairs slightly outnumber the resident workgroups run through persistent
+    workgroups that hand pairs over between iterations (agent-scope release/acquire).  Forced on
+    and off here: states must be bit-identical, whatever workgroup ran which iteration."""
+    from icp_amd import synth
+    crit = icp.make_criteria(max_iterations=40, transform_tol=(1e-4, 1e-4))
+    for dim, n, method, P in [(3, 600, "vanilla", 700), (3, 600, "trimmed", 300), (2, 500, "trimmed", 900)]:
+        s, t, off, _ = synth.config5_pairs(range(P), dim, n)
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("ICPX_SCHED", mode)
+            res[mode] = icp.converge_batch(dim, method, s, off, t, off, crit)
+        monkeypatch.delenv("ICPX_SCHED")
+        for a, b in zip(res["0"], res["1"]):
+            assert np.array_equal(a, b, equal_nan=True), (dim, method)
+        assert res["0"][1].min() >= 1 and len(set(res["0"][1].tolist())) > 1  # ragged iteration counts
+
+
 def test_device_resident_inputs_and_outputs(icp, scans):
     """torch CUDA tensors go into the C ABI as device pointers (no host staging)."""
     import torch
