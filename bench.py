@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="pairs per dim timed on the CPU")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="pairs per dim timed on the CPU")
     args = ap.parse_args()
 
     import torch
@@ -155,7 +155,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp64",
-                "kernel": "pair_kernel<3,vanilla,8,512> (fused 3D converge, one workgroup per pair)",
+                "kernel": "pair_kernel<3,vanilla,8,512> (fused 3D converge; persistent workgroups, one pair-iteration per task)",
                 "achieved": achieved,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -163,7 +163,7 @@ def main():
                 "frac_of_unfused_peak": achieved / (FP64_PEAK_TFLOPS / 2),
                 "launch_ms": k3,
                 "flops_per_launch": flops3,
-                "traffic": None,
+                "traffic": measured_traffic(),
             },
         }
         if not args.no_extras and world == 1:
@@ -173,6 +173,22 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_b_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+    same command).  PMC counters cannot be read from inside this process; None when absent."""
+    path = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+        for name, v in k.items():
+            if "pair_kernel<3, 0" in name:
+                return v["hbm_bytes_per_launch_raw"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def extras(torch, icp_amd, synth, dev, local_rank, stream):
