@@ -3,7 +3,10 @@
 //
 // One iteration = 5 launches chained on the stream, no host round trip:
 //   lg_nn      c = step*c (3D, vanilla_3d.cpp:91), exact grid NN of every source point
-//              (vanilla_3d.cpp:30-45), neighbour distance / selection flag (trimmed_3d.cpp:98)
+//              (vanilla_3d.cpp:30-45), neighbour distance / selection flag (trimmed_3d.cpp:98);
+//              trimmed ICP2: NN of transform*a with squared-distance cost (trimmed.cpp:95-109),
+//              then a stable radix sort of (cost, point) and the best-overlap_rate selection
+//              (trimmed.cpp:55-62)
 //   lg_sum1    TREE64 levels 1-2 of the centroid sums (geo.h:33-37 on the selected pairs)
 //   lg_fin1    remaining levels, centroids
 //   lg_sum2    TREE64 levels 1-2 of the cross-covariance (vanilla_3d.cpp:51)
@@ -16,6 +19,8 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+
+#include <hipcub/hipcub.hpp>
 
 #include "icpx_grid.h"
 #include "icpx_large.h"
@@ -52,6 +57,11 @@ struct LargeIcp {
     int nblk = 0;
     GridIndex* grid = nullptr;
     DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
+    // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
+    DevBuf sort_keys, sort_iota, sort_order, sort_tmp;
+    size_t sort_tmp_bytes = 0;
+    int64_t new_n = 0;
+    bool sorted = false;  // an iterate has run since begin: matches are in sorted order (Q9)
     int* h_done = nullptr;  // pinned
 };
 
@@ -81,9 +91,10 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess) {
     dev->cost_sum = 0.0;
 }
 
-// NN stage.  SETUP2D: Vanilla::setup's compute_matches on the untransformed source
-// (vanilla.cpp:68-88); otherwise the 3D per-iteration stage.
-template <int D, int METHOD, bool SETUP2D>
+// NN stage.  MODE 0: the 3D per-iteration stage.  MODE 1: Vanilla::setup's compute_matches on the
+// untransformed source (vanilla.cpp:68-88).  MODE 2: Trimmed::compute_matches on transform*a with
+// the squared distance as cost (trimmed.cpp:95-109).
+template <int D, int METHOD, int MODE>
 __global__ void __launch_bounds__(256)
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
@@ -93,9 +104,18 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double q[D];
-    if (SETUP2D) {
+    if (MODE == 1) {
 #pragma unroll
         for (int d = 0; d < D; d++) q[d] = src[i * D + d];
+    } else if (MODE == 2) {
+        Xf<D> X;
+#pragma unroll
+        for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+        XfRows<D> xr = xf_rows<D>(X);
+        double p[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) p[d] = src[i * D + d];
+        xf_apply<D>(xr, p, q);  // a_current = transform * a, trimmed.cpp:40
     } else {
         // c = T * c with the step the previous iteration produced (identity after begin)
         Xf<D> S;
@@ -112,10 +132,27 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     double best;
     int bi, visited = 0;
     grid_query<D>(gp, recs, start, q, best, bi, visited);
-    double c = __builtin_sqrt(__builtin_sqrt(best));  // sqrt of kdtree.h:126's Euclidean distance
     nb_idx[i] = bi;
-    nb_cost[i] = c;
-    sel[i] = (D == 3 && METHOD == ICPX_TRIMMED) ? (c <= max_distance ? 1 : 0) : 1;
+    if (MODE == 2) {
+        nb_cost[i] = best;  // trimmed.cpp:101 squaredNorm; selection comes from lg_select_kernel
+    } else {
+        double c = __builtin_sqrt(__builtin_sqrt(best));  // sqrt of kdtree.h:126's Euclidean distance
+        nb_cost[i] = c;
+        sel[i] = (D == 3 && METHOD == ICPX_TRIMMED) ? (c <= max_distance ? 1 : 0) : 1;
+    }
+}
+
+__global__ void lg_iota_kernel(int64_t n, uint32_t* __restrict__ v) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = static_cast<uint32_t>(i);
+}
+
+// trimmed.cpp:57-62: the first new_n matches of the sorted order are kept
+__global__ void lg_select_kernel(const LargeDev* dev, int respect_done, int64_t n, int64_t new_n,
+                                 const uint32_t* __restrict__ order, uint8_t* __restrict__ sel) {
+    if (respect_done && dev->st.done) return;
+    int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r < n) sel[order[r]] = r < new_n ? 1 : 0;
 }
 
 // TREE64 levels 1 and 2 over this block's 4096 points.  f(i, vals) gives point i's NV terms.
@@ -312,8 +349,8 @@ __global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx
 
 template <int D, int METHOD>
 __global__ void __launch_bounds__(kBlk)
-lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, int nblk, int check,
-               icpx_criteria crit, double clock_to_s, double host_elapsed_s) {
+lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, int nblk, double n_points,
+               int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s) {
     __shared__ double lds[64];
     constexpr int XN = (D + 1) * (D + 1);
     if (respect_done && dev->st.done) return;
@@ -337,7 +374,9 @@ lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
             dev->step[e] = step.m[e];
         }
         dev->st.iteration_count += 1;
-        // cost: 2D vanilla's matches never change (vanilla.cpp:80); ICP3 never fills them (Q4)
+        // cost: 2D vanilla's matches never change (vanilla.cpp:80); ICP3 never fills them (Q4);
+        // trimmed ICP2 rates the matches this iteration computed (icp.h:149-155)
+        if (D == 2 && METHOD == ICPX_TRIMMED) dev->st.cost = __builtin_sqrt(dev->cost_sum / n_points);
         if (check) {
             double el = host_elapsed_s + static_cast<double>(wall_clock64() - dev->st.start_clock) * clock_to_s;
             if (should_terminate<D>(crit, dev->st, el)) {
@@ -351,9 +390,16 @@ lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
     }
 }
 
-__global__ void lg_matches_kernel(int64_t n, const int64_t* __restrict__ nb_idx, int64_t* __restrict__ point) {
-    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) point[i] = i;
+// matches in `order` (sorted, trimmed ICP2 after an iterate) or in point order (order == null)
+__global__ void lg_matches_kernel(int64_t n, const uint32_t* __restrict__ order, const int64_t* __restrict__ nb_idx,
+                                  const double* __restrict__ nb_cost, int64_t* __restrict__ point,
+                                  int64_t* __restrict__ pair, double* __restrict__ cost) {
+    int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int64_t i = order ? static_cast<int64_t>(order[r]) : r;
+    point[r] = i;
+    pair[r] = nb_idx[i];
+    cost[r] = nb_cost[i];
 }
 
 }  // namespace
@@ -551,7 +597,7 @@ void large_destroy(LargeIcp* lg) {
     if (!lg) return;
     (void)hipStreamSynchronize(lg->stream);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
-                      &lg->cntp, &lg->dev})
+                      &lg->cntp, &lg->dev, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp})
         b->release();
     grid_destroy(lg->grid);
     if (lg->h_done) (void)hipHostFree(lg->h_done);
@@ -589,7 +635,8 @@ int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double hos
     ICPX_HIP(hipGetLastError());
     if (D == 2) {
         unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
-        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, true>), dim3(nb), dim3(256), 0, lg->stream, dev, 0,
+        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, METHOD == ICPX_TRIMMED ? 2 : 1>), dim3(nb), dim3(256), 0,
+                           lg->stream, dev, 0,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
                            lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
@@ -606,24 +653,41 @@ template <int D, int METHOD>
 int enqueue_iteration(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
     LargeDev* dev = lg->dev.as<LargeDev>();
     const int respect = check;
-    if (D == 3) {
+    if (D == 3 || METHOD == ICPX_TRIMMED) {
         unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
-        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, false>), dim3(nb), dim3(256), 0, lg->stream, dev, respect,
-                           lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
+        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, D == 3 ? 0 : 2>), dim3(nb), dim3(256), 0, lg->stream, dev,
+                           respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
                            lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+        ICPX_HIP(hipGetLastError());
+    }
+    if (D == 2 && METHOD == ICPX_TRIMMED) {
+        // std::sort by cost (trimmed.cpp:55-56) made total: a stable LSD radix sort over the
+        // cost's bit pattern (costs are >= 0, so bit order is numeric order) with the point index
+        // as payload yields the (cost, point) order.  After `done` the inputs no longer change,
+        // so the redundant sorts of a chunk's tail reproduce the same arrays.
+        ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(lg->sort_tmp.p, lg->sort_tmp_bytes,
+                                                    lg->nb_cost.as<unsigned long long>(),
+                                                    lg->sort_keys.as<unsigned long long>(),
+                                                    lg->sort_iota.as<uint32_t>(), lg->sort_order.as<uint32_t>(),
+                                                    static_cast<int>(lg->n), 0, 64, lg->stream));
+        unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+        hipLaunchKernelGGL(lg_select_kernel, dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n, lg->new_n,
+                           lg->sort_order.as<uint32_t>(), lg->sel.as<uint8_t>());
         ICPX_HIP(hipGetLastError());
     }
     ICPX_TRY((enqueue_sums<D, METHOD>(lg, respect, false)));
     ICPX_TRY((enqueue_sums<D, METHOD>(lg, respect, true)));
     hipLaunchKernelGGL((lg_fin2_kernel<D, METHOD>), dim3(1), dim3(kBlk), 0, lg->stream, dev, respect,
-                       lg->part.as<double>(), lg->nblk, check, crit, lg->clock_to_s, host_elapsed_s);
+                       lg->part.as<double>(), lg->nblk, static_cast<double>(lg->n), check, crit, lg->clock_to_s,
+                       host_elapsed_s);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
 
 #define LG_DISPATCH(fn, lg, ...)                                                             \
-    ((lg)->dim == 2 ? fn<2, ICPX_VANILLA>(lg, __VA_ARGS__)                                   \
+    ((lg)->dim == 2 ? ((lg)->method == ICPX_VANILLA ? fn<2, ICPX_VANILLA>(lg, __VA_ARGS__)   \
+                                                    : fn<2, ICPX_TRIMMED>(lg, __VA_ARGS__))  \
                     : ((lg)->method == ICPX_VANILLA ? fn<3, ICPX_VANILLA>(lg, __VA_ARGS__)   \
                                                     : fn<3, ICPX_TRIMMED>(lg, __VA_ARGS__)))
 
@@ -638,9 +702,6 @@ icpx_criteria zero_criteria() {
 int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* target, int64_t m,
                 const double* guess) {
     const int D = lg->dim;
-    if (D == 2 && lg->method == ICPX_TRIMMED)
-        return fail(ICPX_ERR_UNSUPPORTED,
-                    "trimmed ICP2 beyond the fused kernel's limits (n <= 4096, target in LDS) is not implemented yet");
     if (n <= 0 || m <= 0) return fail(ICPX_ERR_INVALID, "large path needs non-empty clouds");
     if (n > kLargeMaxN) return fail(ICPX_ERR_UNSUPPORTED, "source cloud above %lld points", (long long)kLargeMaxN);
     lg->n = n;
@@ -662,11 +723,33 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     // c = a (vanilla_3d.cpp:72): the guess is NOT applied to the running cloud (Q5)
     ICPX_HIP(hipMemcpyAsync(lg->cur.p, lg->src.p, sizeof(double) * D * n, hipMemcpyDeviceToDevice, lg->stream));
     ICPX_HIP(hipMemsetAsync(lg->sel.p, 1, n, lg->stream));
+    lg->sorted = false;
+    if (D == 2 && lg->method == ICPX_TRIMMED) {
+        // trimmed.cpp:57-58 (overlap_rate > 1 would read out of range there; clamped here)
+        long long k = static_cast<long long>(lg->prm.overlap_rate * static_cast<double>(n));
+        lg->new_n = std::min<long long>(std::max<long long>(k, 1), n);
+        ICPX_TRY(lg->sort_keys.reserve(sizeof(unsigned long long) * n));
+        ICPX_TRY(lg->sort_iota.reserve(sizeof(uint32_t) * n));
+        ICPX_TRY(lg->sort_order.reserve(sizeof(uint32_t) * n));
+        size_t bytes = 0;
+        ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, lg->nb_cost.as<unsigned long long>(),
+                                                    lg->sort_keys.as<unsigned long long>(),
+                                                    lg->sort_iota.as<uint32_t>(), lg->sort_order.as<uint32_t>(),
+                                                    static_cast<int>(n), 0, 64, lg->stream));
+        lg->sort_tmp_bytes = bytes ? bytes : 1;
+        ICPX_TRY(lg->sort_tmp.reserve(lg->sort_tmp_bytes));
+        hipLaunchKernelGGL(lg_iota_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, lg->stream, n,
+                           lg->sort_iota.as<uint32_t>());
+        ICPX_HIP(hipGetLastError());
+    }
     ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
     return LG_DISPATCH(enqueue_setup, lg, 0, zero_criteria(), 0.0);
 }
 
-int large_iterate(LargeIcp* lg) { return LG_DISPATCH(enqueue_iteration, lg, 0, zero_criteria(), 0.0); }
+int large_iterate(LargeIcp* lg) {
+    lg->sorted = true;
+    return LG_DISPATCH(enqueue_iteration, lg, 0, zero_criteria(), 0.0);
+}
 
 int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_clock::time_point t0,
                    icpx_state* out) {
@@ -700,6 +783,7 @@ int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_
     std::memset(&res, 0, sizeof(res));
     res.cost = st.cost;
     res.iteration_count = st.iteration_count;
+    if (st.iteration_count > 0) lg->sorted = true;
     const int XN = (lg->dim + 1) * (lg->dim + 1);
     for (int e = 0; e < XN; e++) res.transform[e] = st.transform[e];
     ICPX_HIP(hipMemcpy(out, &res, sizeof(res), hipMemcpyDefault));
@@ -720,23 +804,29 @@ int large_transform(LargeIcp* lg, double* out) {
 }
 
 int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost) {
-    // 2D vanilla only (3D is answered by the caller): matches stay in point order
+    // 2D only (3D is answered by the caller).  Vanilla: point order.  Trimmed: point order after
+    // begin, the sorted order Trimmed::iterate leaves behind (trimmed.cpp:55-56) afterwards.
     const int64_t n = lg->n;
-    if (point) {
-        DevBuf tmp;
-        ICPX_TRY(tmp.reserve(sizeof(int64_t) * n));
+    const bool by_order = lg->method == ICPX_TRIMMED && lg->sorted;
+    DevBuf tp, tq, tc;
+    int rc = tp.reserve(sizeof(int64_t) * n);
+    if (rc == ICPX_OK) rc = tq.reserve(sizeof(int64_t) * n);
+    if (rc == ICPX_OK) rc = tc.reserve(sizeof(double) * n);
+    if (rc == ICPX_OK) {
         hipLaunchKernelGGL(lg_matches_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, lg->stream, n,
-                           lg->nb_idx.as<int64_t>(), tmp.as<int64_t>());
+                           by_order ? lg->sort_order.as<uint32_t>() : nullptr, lg->nb_idx.as<int64_t>(),
+                           lg->nb_cost.as<double>(), tp.as<int64_t>(), tq.as<int64_t>(), tc.as<double>());
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(point, tmp.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream);
+        if (e == hipSuccess && point) e = hipMemcpyAsync(point, tp.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream);
+        if (e == hipSuccess && pair) e = hipMemcpyAsync(pair, tq.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream);
+        if (e == hipSuccess && cost) e = hipMemcpyAsync(cost, tc.p, sizeof(double) * n, hipMemcpyDefault, lg->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(lg->stream);
-        tmp.release();
-        if (e != hipSuccess) return fail(ICPX_ERR_HIP, "matches copy failed: %s", hipGetErrorString(e));
+        if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "matches copy failed: %s", hipGetErrorString(e));
     }
-    if (pair) ICPX_HIP(hipMemcpyAsync(pair, lg->nb_idx.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream));
-    if (cost) ICPX_HIP(hipMemcpyAsync(cost, lg->nb_cost.p, sizeof(double) * n, hipMemcpyDefault, lg->stream));
-    ICPX_HIP(hipStreamSynchronize(lg->stream));
-    return ICPX_OK;
+    tp.release();
+    tq.release();
+    tc.release();
+    return rc;
 }
 
 int large_neighbors(LargeIcp* lg, int64_t* idx, double* dist) {

@@ -248,6 +248,51 @@ def test_grid_forced_on_small_clouds_uses_large_path(icp, ob, scans):
         assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
 
 
+@pytest.mark.parametrize("overlap", [0.9, 0.5, 1.0, 1e-9])
+def test_trimmed2d_large_path(icp, ob, scans, overlap):
+    """Trimmed ICP2 beyond the fused kernel's limits (and nn = grid on scan-sized clouds): NN of
+    transform*a, radix-sorted (cost, point) selection, masked TREE64 sums — every iteration's
+    transform, cost and sorted matches equal the oracle's bits."""
+    from icp_amd import synth
+    cases = [("scan1_grid", *scans[1], "grid")]
+    s, t, _, _ = synth.config5_pairs([4242], 2, 9000)
+    cases.append(("n9000", s[:9000], t[:7777], None))
+    # exact cost ties: duplicated source points and a lattice target
+    rng = np.random.default_rng(3)
+    lat = rng.integers(0, 40, (6000, 2)).astype(float)
+    cases.append(("ties", np.concatenate([lat[:3000], lat[:3000]]) + 0.25, lat, None))
+    for name, a, b, nn in cases:
+        cfg = icp.Config()
+        cfg.set("overlap_rate", overlap)
+        if nn:
+            cfg.set("nn", nn)
+        x = icp.ICP2.from_method("trimmed", cfg)
+        o = dev_oracle(ob, 2, "trimmed", overlap_rate=overlap)
+        g = np.eye(3)
+        g[:2, 2] = (0.03, -0.02)
+        x.begin(a, b, g)
+        o.begin(a, b, g)
+        assert x.calculate_cost() == o.calculate_cost(), name
+        for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+            assert np.array_equal(u, v), name
+        for it in range(4):
+            x.iterate()
+            o.iterate()
+            assert np.array_equal(x.current_transform(), o.current_transform()), (name, it)
+            assert x.calculate_cost() == o.calculate_cost(), (name, it)
+            for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+                assert np.array_equal(u, v), (name, it)
+        # whole converge through the driver, device-side termination
+        crit = dict(max_iterations=20, transform_tol=(1e-5, 1e-5))
+        d = driver(icp, icp.ICP2, "trimmed", crit, cfg)
+        r = d.converge(a, b)
+        ro = o.converge(a, b, None, ob.make_criteria(**crit))
+        assert r.iteration_count == ro.iteration_count, name
+        assert np.array_equal(r.transform, ro.transform) and r.cost == ro.cost, name
+        for u, v in zip(d.icp_.get_matches_arrays(), o.get_matches()):
+            assert np.array_equal(u, v), name
+
+
 def test_driver_criteria_on_device(icp, ob, scans):
     a, b = scans[1]
     for crit in [dict(max_iterations=5), dict(max_iterations=0), dict(min_iterations=7, max_iterations=50, stop_cost=1e9),
@@ -395,12 +440,14 @@ def test_error_behaviour(icp):
     assert lib.icpx_destroy(h) == L.OK
     assert lib.icpx_destroy(None) == L.OK
     assert lib.icpx_iterate(None) == L.ERR_INVALID
-    # trimmed ICP2 beyond the fused limits is not implemented: a clear error, not a wrong answer
-    big = np.random.default_rng(0).normal(size=(5000, 2))
-    x = icp.ICP2.from_method("trimmed")
-    with pytest.raises(icp.IcpxError) as e:
-        x.begin(big, big)
-    assert e.value.code == L.ERR_UNSUPPORTED
+    # a source cloud above the multi-kernel path's limit: a clear error, not a wrong answer
+    h = L._vp()
+    assert lib.icpx_create(2, 1, None, C.byref(h)) == L.OK
+    st = L.State()
+    crit = icp.make_criteria(max_iterations=1)
+    assert lib.icpx_converge(h, a.ctypes.data, (1 << 24) + 1, a.ctypes.data, 3, g.ctypes.data,
+                             C.byref(crit), C.byref(st)) == L.ERR_UNSUPPORTED
+    assert lib.icpx_destroy(h) == L.OK
 
 
 # ------------------------------------------------------------------------------------------
