@@ -98,6 +98,7 @@ int next_pow2(int v) {
 
 struct PairGeom {
     int qpt, threads, tcap, scap;
+    bool filter;  // f32 target copy reserved in LDS (nn_filtered)
     size_t lds;
 };
 
@@ -121,7 +122,12 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g) {
     r.tcap = static_cast<int>((m + 3) & ~int64_t(3));  // targets are consumed four at a time
     if (r.tcap < 4) r.tcap = 4;
     r.scap = (dim == 2 && method == ICPX_TRIMMED) ? next_pow2(static_cast<int>(n)) : 0;
-    r.lds = pair_lds_bytes(dim, r.tcap, r.scap);
+    // the packed-f32 candidate filter needs 4 more bytes of LDS per target coordinate; 2D vanilla
+    // searches once per begin and never uses it.  Development override: ICPX_FILTER=0
+    const char* fe = std::getenv("ICPX_FILTER");
+    r.filter = !(dim == 2 && method == ICPX_VANILLA) && !(fe && fe[0] == '0') &&
+               pair_lds_bytes(dim, r.tcap, r.scap, true) <= kMaxLds;
+    r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter);
     if (r.lds > kMaxLds) return false;
     if (g) *g = r;
     return true;
@@ -193,6 +199,7 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     if (n_pairs <= 0) return ICPX_OK;
     pb.lds_target_cap = g.tcap;
     pb.lds_sort_cap = g.scap;
+    pb.use_filter = g.filter ? 1 : 0;
     if (pb.dim == 2) {
         if (pb.method == ICPX_VANILLA) return launch_dm<2, ICPX_VANILLA>(pb, n_pairs, g, stream);
         return launch_dm<2, ICPX_TRIMMED>(pb, n_pairs, g, stream);
@@ -210,7 +217,7 @@ icpx_criteria no_criteria() {
 // per-device grow-only workspace for the handle-free entry points
 struct Workspace {
     std::mutex mu;
-    DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur;
+    DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
 };
 Workspace& workspace(int device) {
     static std::mutex mu;
@@ -235,7 +242,7 @@ struct icpx_ctx {
     bool begun = false;
     bool large = false;
     PairGeom geom{};
-    DevBuf src, dst, cur, off, guess, m_point, m_pair, m_cost, pair_tmp, state, out;
+    DevBuf src, dst, cur, off, guess, m_point, m_pair, m_cost, pair_tmp, seeds, state, out;
     LargeIcp* lg = nullptr;
 };
 
@@ -258,6 +265,7 @@ int upload_pair(icpx_ctx* h, const double* source, int64_t n, const double* targ
     ICPX_TRY(h->m_pair.reserve(sizeof(int64_t) * (n > 0 ? n : 1)));
     ICPX_TRY(h->m_cost.reserve(sizeof(double) * (n > 0 ? n : 1)));
     ICPX_TRY(h->pair_tmp.reserve(sizeof(int32_t) * (n > 0 ? n : 1)));
+    ICPX_TRY(h->seeds.reserve(sizeof(int32_t) * (n > 0 ? n : 1)));
     ICPX_TRY(h->state.reserve(sizeof(PairState)));
     ICPX_TRY(h->out.reserve(sizeof(icpx_state)));
     if (n > 0) ICPX_HIP(hipMemcpyAsync(h->src.p, source, sizeof(double) * D * n, hipMemcpyDefault, h->stream));
@@ -286,6 +294,7 @@ void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
     pb.m_pair = h->m_pair.as<int64_t>();
     pb.m_cost = h->m_cost.as<double>();
     pb.pair_tmp = h->pair_tmp.as<int32_t>();
+    pb.seeds = h->seeds.as<int32_t>();
     pb.states = h->state.as<PairState>();
     pb.out_states = h->out.as<icpx_state>();
     pb.crit = no_criteria();
@@ -371,7 +380,7 @@ int icpx_destroy(icpx_handle h) {
     (void)g.enter(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->src, &h->dst, &h->cur, &h->off, &h->guess, &h->m_point, &h->m_pair,
-                      &h->m_cost, &h->pair_tmp, &h->state, &h->out})
+                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out})
         b->release();
     if (h->lg) large_destroy(h->lg);
     delete h;
@@ -620,6 +629,11 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
     if (dim == 3) {
         ICPX_TRY(ws.cur.reserve(sizeof(double) * 3 * (n_total > 0 ? n_total : 1)));
         pb.cur = ws.cur.as<double>();
+    }
+    if (geom.filter) {
+        // previous nearest neighbours: the filtered search's seeds travel with the pair too
+        ICPX_TRY(ws.seeds.reserve(sizeof(int32_t) * (n_total > 0 ? n_total : 1)));
+        pb.seeds = ws.seeds.as<int32_t>();
     }
     pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ICPX_TRY(launch_pairs(pb, n_pairs, geom, stream));

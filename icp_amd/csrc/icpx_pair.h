@@ -54,6 +54,9 @@ struct PairBatch {
     int32_t* sched_done;       // number of pairs in state 3
     int32_t n_pairs;
     int32_t sched_steps;       // iterations per task
+    // packed-f32 candidate filter in front of the exact f64 search (nn_filtered below)
+    int32_t use_filter;        // the launch reserved the f32 target copy in LDS
+    int32_t* seeds;            // n_total: previous nearest neighbour by point, carried between launches / tasks; may be nullptr
 };
 
 template <int D>
@@ -63,10 +66,17 @@ struct LdsView {
     double* bc;      // broadcast
     uint64_t* skey;  // sort keys
     uint32_t* sval;  // sort values
+    float* tf[3];    // f32 copy of the target SoA (candidate filter), null when not reserved
 };
 
+inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
+    size_t b = sizeof(double) * (static_cast<size_t>(dim) * tcap + kGsValues * kGsStride + kBcDoubles) +
+               static_cast<size_t>(scap) * 12;
+    return (b + 15) & ~static_cast<size_t>(15);
+}
+
 template <int D>
-ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap) {
+ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap, int filter) {
     LdsView<D> v;
     double* p = base;
     for (int d = 0; d < D; d++) {
@@ -80,12 +90,13 @@ ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap) {
     p += kBcDoubles;
     v.skey = reinterpret_cast<uint64_t*>(p);
     v.sval = reinterpret_cast<uint32_t*>(v.skey + scap);
+    float* f = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + pair_lds_filter_offset(D, tcap, scap));
+    for (int d = 0; d < 3; d++) v.tf[d] = (filter && d < D) ? f + static_cast<size_t>(d) * tcap : nullptr;
     return v;
 }
 
-inline size_t pair_lds_bytes(int dim, int tcap, int scap) {
-    return sizeof(double) * (static_cast<size_t>(dim) * tcap + kGsValues * kGsStride + kBcDoubles) +
-           static_cast<size_t>(scap) * 12;
+inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter) {
+    return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0);
 }
 
 // brute-force NN of QPT register-resident queries against the LDS target cloud.
@@ -152,6 +163,131 @@ ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, dou
         }
         bidx[k] = idx;
     }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Filter threshold: every target whose exact d2 is <= d2max has a filter value (packed-f32 squared
+// distance, below) <= the returned bound.  `err` bounds the Euclidean error of the f32 difference
+// vector.  Margins: (float)d2max and sqrtf lose <= 2^-23 relative, the filter value gains
+// <= (1+2^-24)^3; the factors below (2^-21, 2^-19, 2^-18) and the absolute 1e-30 (f32 underflow
+// range) cover them with room.
+ICPX_DEV float filter_threshold(double d2max, float err) {
+    float d2f = static_cast<float>(d2max) * 1.0000005f + 1e-30f;
+    float s = __builtin_sqrtf(d2f) * 1.000002f + err;
+    return s * s * 1.000004f + 1e-30f;
+}
+
+// exact (d2, j) update of query slot k against the four targets of block `blk` (lanes with blk < 0 idle)
+template <int D>
+ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, double& best, int& bidx) {
+    const bool act = blk >= 0;
+    const int jb = act ? blk : 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        double df = L.t[0][jb + u] - q[0];
+        double acc = df * df;
+#pragma unroll
+        for (int d = 1; d < D; d++) {
+            df = L.t[d][jb + u] - q[d];
+            acc = acc + df * df;
+        }
+        bool better = act && (acc < best || (acc == best && jb + u < bidx));
+        best = better ? acc : best;
+        bidx = better ? jb + u : bidx;
+    }
+}
+
+// Same result as nn_lds — the lexicographic minimum of (d2, j) with d2 in unfused f64 — at a
+// third of the VALU work, for iterations that have a seed (the previous iteration's neighbour):
+//   1. seed: exact d2 to the seed target bounds the answer from above;
+//   2. filter: ALL targets are scanned in packed f32 (v_pk_add/mul/fma_f32: two targets per
+//      instruction at the f64 instruction rate; 15 VALU instructions per 4 targets and query
+//      instead of ~40), four at a time; a block whose smallest filter value is not above the
+//      query's threshold is a candidate.  The threshold comes with a proven error bound
+//      (filter_threshold): rounding coordinates to f32 moves a difference vector by at most
+//      err = 2^-22 (max|target| + max|query|), so no target with exact d2 <= the current best
+//      can be missed — the seed and every tie included;
+//   3. exact: candidate blocks are re-evaluated in f64 with the reference's expression and the
+//      (d2, j) rule; each improvement tightens the threshold.  One pending block per query slot
+//      is kept in a register; a second candidate for the same slot flushes the first (wave-wide).
+// Waves whose coordinates are not finite or exceed 1e18 in magnitude (f32 squares would overflow)
+// use nn_lds.  bidx holds the seeds on entry.
+template <int D, int QPT>
+ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m, int m4, double t_absmax,
+                          double (&best)[QPT], int (&bidx)[QPT]) {
+    bool bad = false;
+    float err[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        double mq = __builtin_fabs(q[k][0]);
+#pragma unroll
+        for (int d = 1; d < D; d++) mq = __builtin_fmax(mq, __builtin_fabs(q[k][d]));
+#pragma unroll
+        for (int d = 0; d < D; d++) bad = bad || !(__builtin_fabs(q[k][d]) < 1e18);
+        bad = bad || !(t_absmax < 1e18);
+        err[k] = static_cast<float>((t_absmax + mq) * (1.001 / 4194304.0));  // 2^-22, sqrt(3) <= 2 folded in
+    }
+    if (__any(bad)) {
+        nn_lds<D, QPT>(q, L, m4, best, bidx);
+        return;
+    }
+    f32x2 qf[QPT][D];
+    float thr[QPT];
+    int pend[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        int j = bidx[k];
+        j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+        double df = L.t[0][j] - q[k][0];
+        double acc = df * df;
+#pragma unroll
+        for (int d = 1; d < D; d++) {
+            df = L.t[d][j] - q[k][d];
+            acc = acc + df * df;
+        }
+        best[k] = acc;
+        bidx[k] = j;
+        thr[k] = filter_threshold(acc, err[k]);
+        pend[k] = -1;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            float v = static_cast<float>(q[k][d]);
+            qf[k][d] = (f32x2){v, v};
+        }
+    }
+    for (int jb = 0; jb < m4; jb += 4) {
+        f32x4 tc[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) tc[d] = *reinterpret_cast<const f32x4*>(L.tf[d] + jb);
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            f32x2 e0 = tc[0].xy - qf[k][0], e1 = tc[0].zw - qf[k][0];
+            f32x2 s0 = e0 * e0, s1 = e1 * e1;
+#pragma unroll
+            for (int d = 1; d < D; d++) {
+                e0 = tc[d].xy - qf[k][d];
+                e1 = tc[d].zw - qf[k][d];
+                s0 = __builtin_elementwise_fma(e0, e0, s0);
+                s1 = __builtin_elementwise_fma(e1, e1, s1);
+            }
+            float mn = __builtin_fminf(__builtin_fminf(s0.x, s0.y), __builtin_fminf(s1.x, s1.y));
+            bool cand = !(mn > thr[k]);
+            if (__any(cand)) {
+                if (__any(cand && pend[k] >= 0)) {
+                    double before = best[k];
+                    exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
+                    pend[k] = -1;
+                    if (best[k] < before) thr[k] = filter_threshold(best[k], err[k]);
+                }
+                pend[k] = cand ? jb : pend[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QPT; k++)
+        if (__any(pend[k] >= 0)) exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
 }
 
 // TREE64 sum of NV values per point.  f(k, vals) fills the NV contributions of point tid + k*T
@@ -242,14 +378,28 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     const double* __restrict__ src = pb.src + s0 * D;
     const double* __restrict__ dst = pb.dst + d0 * D;
     PairState* st = pb.states + p;
-    LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap);
+    const bool filter = pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
+    LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
     const bool empty = (n == 0 || m == 0);
 
-    // ---- stage the target cloud into LDS as SoA ----
+    // ---- stage the target cloud into LDS as SoA (+ its f32 copy and max |coordinate|) ----
     const int m4 = (m + 3) & ~3;
+    double t_absmax = 0.0;
     for (int j = tid; j < m4; j += T) {
 #pragma unroll
-        for (int d = 0; d < D; d++) L.t[d][j] = j < m ? dst[static_cast<int64_t>(j) * D + d] : __builtin_inf();
+        for (int d = 0; d < D; d++) {
+            double v = j < m ? dst[static_cast<int64_t>(j) * D + d] : __builtin_inf();
+            L.t[d][j] = v;
+            if (filter) {
+                L.tf[d][j] = static_cast<float>(v);
+                if (j < m) t_absmax = __builtin_fmax(t_absmax, __builtin_fabs(v) < 1e18 ? __builtin_fabs(v) : __builtin_inf());
+            }
+        }
+    }
+    if (filter) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) t_absmax = __builtin_fmax(t_absmax, __shfl_xor(t_absmax, o));
+        if ((tid & 63) == 0) L.bc[16 + (tid >> 6)] = t_absmax;  // step area: first written much later
     }
 
     // ---- per-thread point slots ----
@@ -293,6 +443,18 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         for (int e = 0; e < XN; e++) L.bc[e] = st->transform[e];
     }
     __syncthreads();
+    if (filter) {
+        t_absmax = 0.0;
+        for (int w = 0; w < (T >> 6); w++) t_absmax = __builtin_fmax(t_absmax, L.bc[16 + w]);
+    }
+    // seeds for the filtered search: the previous nearest neighbours.  Trimmed ICP2 has them from
+    // setup on; ICP3 after its first iterate; a resumed launch reloads them.
+    bool have_seed = false;
+    if (filter && !do_setup && pb.seeds && !empty && (D == 2 || st->iteration_count > 0)) {
+#pragma unroll
+        for (int k = 0; k < QPT; k++) pair[k] = valid[k] ? pb.seeds[s0 + tid + k * T] : 0;
+        have_seed = true;
+    }
 
     bool sorted_matches = false;
 
@@ -319,6 +481,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             }
             double best[QPT];
             nn_lds<D, QPT>(q, L, m4, best, pair);
+            have_seed = filter;
 #pragma unroll
             for (int k = 0; k < QPT; k++) {
                 if (METHOD == ICPX_VANILLA) cost[k] = __builtin_sqrt(__builtin_sqrt(best[k]));  // vanilla.cpp:84 on kdtree.h:126
@@ -386,7 +549,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
-                    nn_lds<D, QPT>(cur, L, m4, best, pair);
+                    if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, t_absmax, best, pair);
+                    else nn_lds<D, QPT>(cur, L, m4, best, pair);
+                    have_seed = filter;
 #pragma unroll
                     for (int k = 0; k < QPT; k++) cost[k] = valid[k] ? best[k] : 0.0;
                     // trimming step, trimmed.cpp:55-58: order by (cost, point), keep the first new_n
@@ -425,7 +590,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 double best[QPT];
-                nn_lds<D, QPT>(cur, L, m4, best, pair);
+                if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, t_absmax, best, pair);
+                else nn_lds<D, QPT>(cur, L, m4, best, pair);
+                have_seed = filter;
 #pragma unroll
                 for (int k = 0; k < QPT; k++) {
                     cost[k] = __builtin_sqrt(__builtin_sqrt(best[k]));  // vanilla_3d.cpp:41 on kdtree.h:126
@@ -508,6 +675,11 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     }
 
     // ---- publish ----
+    if (filter && pb.seeds) {
+#pragma unroll
+        for (int k = 0; k < QPT; k++)
+            if (valid[k]) pb.seeds[s0 + tid + k * T] = pair[k];
+    }
     if (D == 3 && pb.cur) {
 #pragma unroll
         for (int k = 0; k < QPT; k++)
