@@ -186,11 +186,8 @@ int launch_dm(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream
         case 20256: return launch_one<D, METHOD, 2, 256>(pb, n_pairs, g, stream);
         case 40256: return launch_one<D, METHOD, 4, 256>(pb, n_pairs, g, stream);
         case 80256: return launch_one<D, METHOD, 8, 256>(pb, n_pairs, g, stream);
-        case 160256: return launch_one<D, METHOD, 16, 256>(pb, n_pairs, g, stream);
-        case 20512: return launch_one<D, METHOD, 2, 512>(pb, n_pairs, g, stream);
         case 40512: return launch_one<D, METHOD, 4, 512>(pb, n_pairs, g, stream);
         case 80512: return launch_one<D, METHOD, 8, 512>(pb, n_pairs, g, stream);
-        case 41024: return launch_one<D, METHOD, 4, 1024>(pb, n_pairs, g, stream);
         default: return fail(ICPX_ERR_INVALID, "no fused kernel for %d queries per lane x %d threads", g.qpt, g.threads);
     }
 }
@@ -644,6 +641,19 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
     ICPX_HIP(hipStreamSynchronize(stream));
     return ICPX_OK;
 }
+
+#ifdef ICPX_STATS
+// development builds only (-DICPX_STATS): read / reset the kernel statistics counters
+int icpx_debug_stats(unsigned long long* out, int reset) {
+    ICPX_HIP(hipDeviceSynchronize());
+    if (out) ICPX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(icpx::g_icpx_stats), sizeof(unsigned long long) * 8));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        ICPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_icpx_stats), z, sizeof(z)));
+    }
+    return ICPX_OK;
+}
+#endif
 
 int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
             int64_t* idx, double* d2, int mode, int device, void* stream_) {

@@ -165,21 +165,56 @@ ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, dou
     }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Filter threshold: every target whose exact d2 is <= d2max has a filter value (packed-f32 squared
-// distance, below) <= the returned bound.  `err` bounds the Euclidean error of the f32 difference
-// vector.  Margins: (float)d2max and sqrtf lose <= 2^-23 relative, the filter value gains
-// <= (1+2^-24)^3; the factors below (2^-21, 2^-19, 2^-18) and the absolute 1e-30 (f32 underflow
-// range) cover them with room.
-ICPX_DEV float filter_threshold(double d2max, float err) {
-    float d2f = static_cast<float>(d2max) * 1.0000005f + 1e-30f;
-    float s = __builtin_sqrtf(d2f) * 1.000002f + err;
-    return s * s * 1.000004f + 1e-30f;
+// development statistics (build with -DICPX_STATS; read with icpx_debug_stats):
+//   0 seeded scans (wave)  1 exact flushes (wave)  2 two-min scans (wave)  3 near-tie lanes  4 slot rescans (wave)
+#ifdef ICPX_STATS
+__device__ unsigned long long g_icpx_stats[8];
+#define ICPX_STAT(slot_, amount_)                                                                    \
+    do {                                                                                             \
+        unsigned long long stat_v_ = (unsigned long long)(amount_);                                  \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_icpx_stats[slot_], stat_v_);                       \
+    } while (0)
+#else
+#define ICPX_STAT(slot_, amount_) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// f32 candidate filter in front of the exact f64 search.
+//
+// Measured on MI355X (tools/micro/rate_probe.hip): a wave64 v_fma_f64 / v_add_f64 / v_pk_*_f32
+// issues every ~5 cycles per SIMD, a plain v_fma_f32 / v_min_f32 every ~2.8.  The exact search
+// costs ~10 f64 instructions per (query, target); the filter below costs 3 plain f32 FMAs.
+//
+// Filter value of target j for query q (both moved by the same offset c0, the centre of the
+// target's bounding box, then rounded to f32: t32, q32):
+//     v_j = |t32_j|^2 - 2 t32_j . q32          ( = |t32_j - q32|^2 - |q32|^2 )
+// computed as fma(tz, -2qz, fma(ty, -2qy, fma(tx, -2qx, |t32|^2))), |t32|^2 once per target and wave.
+// Error budget, u = 2^-24, Mt / Mq = max |coordinate| of the moved targets / of the moved query:
+//   * rounding the moved coordinates to f32 displaces t32 - q32 from the true difference vector
+//     by at most sqrt(D) u (Mt + Mq) <= E = 2^-22 (Mt + Mq)                 (distance domain)
+//   * the f32 arithmetic of v_j is off by at most 6 u (|t32| + |q32|)^2 <= E2 = 24 u (Mt + Mq)^2
+// so every target with exact distance d_j <= B satisfies  v_j <= (B + E)^2 - |q32|^2 + E2.
+// filter_threshold returns an upper bound of that right-hand side for B^2 = d2max; a block of
+// four targets whose smallest v is above it cannot contain a target with d2 <= d2max — ties
+// included — whatever the rounding did.  Candidate blocks are re-evaluated exactly (exact_block),
+// with the reference's expression on the original coordinates and the (d2, j) rule, so the result
+// is the one nn_lds gives, bit for bit.
+// ---------------------------------------------------------------------------------------------
+struct FilterFrame {
+    double c0[3];      // common offset: centre of the target bounding box
+    double t_absmax;   // max |t - c0| over the target cloud; +inf when a coordinate is not finite / >= 1e18
+};
+
+ICPX_DEV float filter_threshold(double d2max, float qn_lo, float e_dist, float e_val) {
+    float d2f = static_cast<float>(d2max) * 1.0000005f + 1e-30f;   // >= d2max
+    float s = __builtin_sqrtf(d2f) * 1.000002f + e_dist;           // >= sqrt(d2max) + E
+    float a = s * s * 1.000004f;                                    // >= (B + E)^2
+    return (a - qn_lo) + (e_val + (a + qn_lo) * 2.4e-7f + 1e-30f);  // f32 roundings of this line: <= 2^-22 (a + qn)
 }
 
-// exact (d2, j) update of query slot k against the four targets of block `blk` (lanes with blk < 0 idle)
+// exact (d2, j) update of one query against the four targets of block `blk` (lanes with blk < 0 idle)
 template <int D>
 ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, double& best, int& bidx) {
     const bool act = blk >= 0;
@@ -199,43 +234,76 @@ ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, do
     }
 }
 
-// Same result as nn_lds — the lexicographic minimum of (d2, j) with d2 in unfused f64 — at a
-// third of the VALU work, for iterations that have a seed (the previous iteration's neighbour):
-//   1. seed: exact d2 to the seed target bounds the answer from above;
-//   2. filter: ALL targets are scanned in packed f32 (v_pk_add/mul/fma_f32: two targets per
-//      instruction at the f64 instruction rate; 15 VALU instructions per 4 targets and query
-//      instead of ~40), four at a time; a block whose smallest filter value is not above the
-//      query's threshold is a candidate.  The threshold comes with a proven error bound
-//      (filter_threshold): rounding coordinates to f32 moves a difference vector by at most
-//      err = 2^-22 (max|target| + max|query|), so no target with exact d2 <= the current best
-//      can be missed — the seed and every tie included;
-//   3. exact: candidate blocks are re-evaluated in f64 with the reference's expression and the
-//      (d2, j) rule; each improvement tightens the threshold.  One pending block per query slot
-//      is kept in a register; a second candidate for the same slot flushes the first (wave-wide).
-// Waves whose coordinates are not finite or exceed 1e18 in magnitude (f32 squares would overflow)
-// use nn_lds.  bidx holds the seeds on entry.
+// per-lane filter operands of the QPT queries; returns false when this lane cannot use the filter
 template <int D, int QPT>
-ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m, int m4, double t_absmax,
-                          double (&best)[QPT], int (&bidx)[QPT]) {
-    bool bad = false;
-    float err[QPT];
+ICPX_DEV bool filter_queries(const double (&q)[QPT][D], const FilterFrame& F, float (&q2)[QPT][D], float (&qn)[QPT],
+                             float& e_dist, float& e_val) {
+    bool ok = F.t_absmax < 1e18;
+    double mq = 0.0;
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
-        double mq = __builtin_fabs(q[k][0]);
+        double nn = 0.0;
 #pragma unroll
-        for (int d = 1; d < D; d++) mq = __builtin_fmax(mq, __builtin_fabs(q[k][d]));
-#pragma unroll
-        for (int d = 0; d < D; d++) bad = bad || !(__builtin_fabs(q[k][d]) < 1e18);
-        bad = bad || !(t_absmax < 1e18);
-        err[k] = static_cast<float>((t_absmax + mq) * (1.001 / 4194304.0));  // 2^-22, sqrt(3) <= 2 folded in
+        for (int d = 0; d < D; d++) {
+            double c = q[k][d] - F.c0[d];
+            ok = ok && (__builtin_fabs(c) < 1e18);
+            mq = __builtin_fmax(mq, __builtin_fabs(c));
+            float f = static_cast<float>(c);
+            q2[k][d] = -2.0f * f;
+            nn = nn + static_cast<double>(f) * static_cast<double>(f);
+        }
+        qn[k] = static_cast<float>(nn * (1.0 - 1.0 / 4194304.0));  // <= |q32|^2
     }
-    if (__any(bad)) {
+    const double mm = F.t_absmax + mq;
+    e_dist = static_cast<float>(mm * (1.001 / 4194304.0));           // 2^-22 (Mt + Mq)
+    e_val = static_cast<float>(mm * mm * (24.3 / 16777216.0));       // 24 u (Mt + Mq)^2
+    return ok;
+}
+
+// smallest filter value of the four targets of a block for one query
+template <int D>
+ICPX_DEV float block_filter_min(const f32x4 (&tc)[D], const f32x4& tn, const float (&q2)[D]) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        float a = __builtin_fmaf(tc[0][u], q2[0], tn[u]);
+#pragma unroll
+        for (int d = 1; d < D; d++) a = __builtin_fmaf(tc[d][u], q2[d], a);
+        v[u] = a;
+    }
+    return __builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3]));
+}
+
+template <int D>
+ICPX_DEV void load_filter_block(const LdsView<D>& L, int jb, f32x4 (&tc)[D], f32x4& tn) {
+#pragma unroll
+    for (int d = 0; d < D; d++) tc[d] = *reinterpret_cast<const f32x4*>(L.tf[d] + jb);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        float a = tc[0][u] * tc[0][u];
+#pragma unroll
+        for (int d = 1; d < D; d++) a = __builtin_fmaf(tc[d][u], tc[d][u], a);
+        tn[u] = a;
+    }
+}
+
+// Seeded search: bidx holds the previous iteration's neighbours.  The exact distance to the seed
+// bounds the answer; ALL targets are scanned through the filter, four at a time; candidate
+// blocks are evaluated exactly and every improvement tightens the threshold.  One pending block
+// per query slot is kept in a register; a second candidate for the same slot flushes the first
+// (wave-wide).  Waves with unusable coordinates take nn_lds.
+template <int D, int QPT>
+ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m, int m4, const FilterFrame& F,
+                          double (&best)[QPT], int (&bidx)[QPT]) {
+    float q2[QPT][D], qn[QPT], e_dist, e_val;
+    const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
+    if (__any(!ok)) {
         nn_lds<D, QPT>(q, L, m4, best, bidx);
         return;
     }
-    f32x2 qf[QPT][D];
     float thr[QPT];
     int pend[QPT];
+    ICPX_STAT(0, 1);
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
         int j = bidx[k];
@@ -249,45 +317,136 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m,
         }
         best[k] = acc;
         bidx[k] = j;
-        thr[k] = filter_threshold(acc, err[k]);
+        thr[k] = filter_threshold(acc, qn[k], e_dist, e_val);
         pend[k] = -1;
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            float v = static_cast<float>(q[k][d]);
-            qf[k][d] = (f32x2){v, v};
-        }
     }
+    constexpr int G = QPT >= 2 ? 2 : 1;  // slots per branch: wider basic blocks schedule better
     for (int jb = 0; jb < m4; jb += 4) {
-        f32x4 tc[D];
+        f32x4 tc[D], tn;
+        load_filter_block<D>(L, jb, tc, tn);
 #pragma unroll
-        for (int d = 0; d < D; d++) tc[d] = *reinterpret_cast<const f32x4*>(L.tf[d] + jb);
+        for (int k0 = 0; k0 < QPT; k0 += G) {
+            bool cand[G];
+            bool any = false;
 #pragma unroll
-        for (int k = 0; k < QPT; k++) {
-            f32x2 e0 = tc[0].xy - qf[k][0], e1 = tc[0].zw - qf[k][0];
-            f32x2 s0 = e0 * e0, s1 = e1 * e1;
-#pragma unroll
-            for (int d = 1; d < D; d++) {
-                e0 = tc[d].xy - qf[k][d];
-                e1 = tc[d].zw - qf[k][d];
-                s0 = __builtin_elementwise_fma(e0, e0, s0);
-                s1 = __builtin_elementwise_fma(e1, e1, s1);
+            for (int g = 0; g < G; g++) {
+                cand[g] = !(block_filter_min<D>(tc, tn, q2[k0 + g]) > thr[k0 + g]);
+                any = any || cand[g];
             }
-            float mn = __builtin_fminf(__builtin_fminf(s0.x, s0.y), __builtin_fminf(s1.x, s1.y));
-            bool cand = !(mn > thr[k]);
-            if (__any(cand)) {
-                if (__any(cand && pend[k] >= 0)) {
-                    double before = best[k];
-                    exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
-                    pend[k] = -1;
-                    if (best[k] < before) thr[k] = filter_threshold(best[k], err[k]);
+            if (__any(any)) {
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const int k = k0 + g;
+                    if (__any(cand[g] && pend[k] >= 0)) {
+                        ICPX_STAT(1, 1);
+                        double before = best[k];
+                        exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
+                        pend[k] = -1;
+                        if (best[k] < before) thr[k] = filter_threshold(best[k], qn[k], e_dist, e_val);
+                    }
+                    pend[k] = cand[g] ? jb : pend[k];
                 }
-                pend[k] = cand ? jb : pend[k];
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < QPT; k++)
         if (__any(pend[k] >= 0)) exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
+}
+
+// Wave-cooperative rescan of single queries: for every lane whose flag is set, the wave takes
+// that lane's query (broadcast), each lane filters the blocks lane, lane + 64, ... and evaluates
+// its candidate blocks exactly; a butterfly over (d2, j) leaves the lexicographic minimum, which
+// the owning lane keeps.  1024 blocks cost 16 steps instead of a 1024-step scan with one useful
+// lane.
+template <int D>
+ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D], float thr, const LdsView<D>& L,
+                          int m4, double& best, int& bidx) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long mask = __ballot(flag);
+    while (mask) {
+        const int src = __ffsll(static_cast<long long>(mask)) - 1;
+        mask &= mask - 1;
+        double qb[D];
+        float q2b[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            qb[d] = __shfl(q[d], src);
+            q2b[d] = __shfl(q2[d], src);
+        }
+        const float thr_b = __shfl(thr, src);
+        double bb = __builtin_inf();
+        int bi = 0x7fffffff;
+        for (int jb = lane * 4; jb < m4; jb += 256) {
+            f32x4 tc[D], tn;
+            load_filter_block<D>(L, jb, tc, tn);
+            if (!(block_filter_min<D>(tc, tn, q2b) > thr_b)) exact_block<D>(qb, L, jb, bb, bi);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            double ob = __shfl_xor(bb, o);
+            int oi = __shfl_xor(bi, o);
+            bool take = ob < bb || (ob == bb && oi < bi);
+            bb = take ? ob : bb;
+            bi = take ? oi : bi;
+        }
+        if (lane == src && bb < __builtin_inf()) {
+            best = bb;
+            bidx = bi;
+        }
+    }
+}
+
+// Seedless search (first search of a pair): ONE filter pass keeps, per query, the smallest
+// block value b1 with its block and the second smallest b2 over all other blocks:
+//     b2' = min(b2, max(b1, v)),  b1' = min(b1, v).
+// The winning block is evaluated exactly; if b2 lies above the threshold of that exact best, no
+// other block can hold a target with d2 <= best and the search is complete.  Otherwise — exact
+// ties and near-ties inside the error budget — the query is rescanned cooperatively (coop_rescan).
+template <int D, int QPT>
+ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m, int m4, const FilterFrame& F,
+                        double (&best)[QPT], int (&bidx)[QPT]) {
+    float q2[QPT][D], qn[QPT], e_dist, e_val;
+    const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
+    if (__any(!ok)) {
+        nn_lds<D, QPT>(q, L, m4, best, bidx);
+        return;
+    }
+    float b1[QPT], b2[QPT];
+    int blk[QPT];
+    ICPX_STAT(2, 1);
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        b1[k] = __builtin_inff();
+        b2[k] = __builtin_inff();
+        blk[k] = 0;
+    }
+    for (int jb = 0; jb < m4; jb += 4) {
+        f32x4 tc[D], tn;
+        load_filter_block<D>(L, jb, tc, tn);
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            float mn = block_filter_min<D>(tc, tn, q2[k]);
+            bool lt = mn < b1[k];
+            b2[k] = __builtin_fminf(b2[k], __builtin_fmaxf(b1[k], mn));
+            b1[k] = __builtin_fminf(b1[k], mn);
+            blk[k] = lt ? jb : blk[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        best[k] = __builtin_inf();
+        bidx[k] = 0;
+        exact_block<D>(q[k], L, blk[k], best[k], bidx[k]);
+        // near-ties (about 0.15 % of the queries on uniform clouds): cooperative rescan
+        const float thr = filter_threshold(best[k], qn[k], e_dist, e_val);
+        const bool again = !(b2[k] > thr);
+        ICPX_STAT(3, __popcll(__ballot(again)));
+        if (__any(again)) {
+            ICPX_STAT(4, 1);
+            coop_rescan<D>(again, q[k], q2[k], thr, L, m4, best[k], bidx[k]);
+        }
+    }
 }
 
 // TREE64 sum of NV values per point.  f(k, vals) fills the NV contributions of point tid + k*T
@@ -382,26 +541,81 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
     const bool empty = (n == 0 || m == 0);
 
-    // ---- stage the target cloud into LDS as SoA (+ its f32 copy and max |coordinate|) ----
+    // ---- stage the target cloud into LDS as SoA ----
     const int m4 = (m + 3) & ~3;
-    double t_absmax = 0.0;
+    double lo[D], hi[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        lo[d] = __builtin_inf();
+        hi[d] = -__builtin_inf();
+    }
+    bool t_bad = false;
     for (int j = tid; j < m4; j += T) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             double v = j < m ? dst[static_cast<int64_t>(j) * D + d] : __builtin_inf();
             L.t[d][j] = v;
-            if (filter) {
-                L.tf[d][j] = static_cast<float>(v);
-                if (j < m) t_absmax = __builtin_fmax(t_absmax, __builtin_fabs(v) < 1e18 ? __builtin_fabs(v) : __builtin_inf());
+            if (filter && j < m) {
+                t_bad = t_bad || !(__builtin_fabs(v) < 1e300);
+                lo[d] = __builtin_fmin(lo[d], v);
+                hi[d] = __builtin_fmax(hi[d], v);
             }
         }
     }
-    if (filter) {
+    // filter frame: bounding-box centre, f32 copy of the moved targets, max |moved coordinate|
+    FilterFrame F;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) t_absmax = __builtin_fmax(t_absmax, __shfl_xor(t_absmax, o));
-        if ((tid & 63) == 0) L.bc[16 + (tid >> 6)] = t_absmax;  // step area: first written much later
+    for (int d = 0; d < 3; d++) F.c0[d] = 0.0;
+    F.t_absmax = __builtin_inf();
+    if (filter) {
+        const int lane = tid & 63, wave = tid >> 6, W = T >> 6;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                lo[d] = __builtin_fmin(lo[d], __shfl_xor(lo[d], o));
+                hi[d] = __builtin_fmax(hi[d], __shfl_xor(hi[d], o));
+            }
+            if (lane == 0) {
+                L.gs[wave * 8 + d] = lo[d];
+                L.gs[wave * 8 + 4 + d] = hi[d];
+            }
+        }
+        const bool wave_bad = __any(t_bad);
+        if (lane == 0) L.gs[wave * 8 + 3] = wave_bad ? 1.0 : 0.0;
+        __syncthreads();
+        bool any_bad = false;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            double l = __builtin_inf(), h = -__builtin_inf();
+            for (int w = 0; w < W; w++) {
+                l = __builtin_fmin(l, L.gs[w * 8 + d]);
+                h = __builtin_fmax(h, L.gs[w * 8 + 4 + d]);
+            }
+            F.c0[d] = m > 0 ? 0.5 * l + 0.5 * h : 0.0;
+        }
+        for (int w = 0; w < W; w++) any_bad = any_bad || L.gs[w * 8 + 3] != 0.0;
+        double amax = 0.0;
+        for (int j = tid; j < m4; j += T) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                double c = L.t[d][j] - F.c0[d];
+                bool real = j < m;
+                // padding: a large finite value, never a candidate and never NaN in the filter
+                L.tf[d][j] = real ? static_cast<float>(c) : 1e18f;
+                if (real) amax = __builtin_fmax(amax, __builtin_fabs(c) < 1e18 ? __builtin_fabs(c) : __builtin_inf());
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) amax = __builtin_fmax(amax, __shfl_xor(amax, o));
+        __syncthreads();  // everyone has read the bounding box before gs is reused
+        if (lane == 0) L.gs[wave] = amax;
+        __syncthreads();
+        amax = 0.0;
+        for (int w = 0; w < W; w++) amax = __builtin_fmax(amax, L.gs[w]);
+        F.t_absmax = any_bad ? __builtin_inf() : amax;
+        // the barrier after the state block below separates these reads from the next use of gs
     }
-
     // ---- per-thread point slots ----
     double a[QPT][D];    // 2D: source points; 3D: running cloud c
     double cost[QPT];    // match cost (2D) / neighbour distance (3D)
@@ -443,10 +657,6 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         for (int e = 0; e < XN; e++) L.bc[e] = st->transform[e];
     }
     __syncthreads();
-    if (filter) {
-        t_absmax = 0.0;
-        for (int w = 0; w < (T >> 6); w++) t_absmax = __builtin_fmax(t_absmax, L.bc[16 + w]);
-    }
     // seeds for the filtered search: the previous nearest neighbours.  Trimmed ICP2 has them from
     // setup on; ICP3 after its first iterate; a resumed launch reloads them.
     bool have_seed = false;
@@ -480,7 +690,8 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            nn_lds<D, QPT>(q, L, m4, best, pair);
+            if (filter) nn_twomin<D, QPT>(q, L, m, m4, F, best, pair);
+            else nn_lds<D, QPT>(q, L, m4, best, pair);
             have_seed = filter;
 #pragma unroll
             for (int k = 0; k < QPT; k++) {
@@ -549,7 +760,8 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
-                    if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, t_absmax, best, pair);
+                    if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, F, best, pair);
+                    else if (filter) nn_twomin<D, QPT>(cur, L, m, m4, F, best, pair);
                     else nn_lds<D, QPT>(cur, L, m4, best, pair);
                     have_seed = filter;
 #pragma unroll
@@ -590,7 +802,8 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 double best[QPT];
-                if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, t_absmax, best, pair);
+                if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, F, best, pair);
+                else if (filter) nn_twomin<D, QPT>(cur, L, m, m4, F, best, pair);
                 else nn_lds<D, QPT>(cur, L, m4, best, pair);
                 have_seed = filter;
 #pragma unroll
@@ -745,6 +958,7 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
     __shared__ int s_key, s_pick;
     const int tid = threadIdx.x;
     const int P = pb.n_pairs;
+    const int home = static_cast<int>(static_cast<long long>(blockIdx.x) * P / gridDim.x);
     for (int guard = 0; guard < (1 << 30); guard++) {
         if (tid == 0) s_key = 0x7fffffff;
         __syncthreads();
@@ -753,9 +967,13 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
             int w = __hip_atomic_load(&pb.sched_state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int st = w & 3;
             if (st <= 1) {
-                // fewest iterations first (longest expected remaining chain), then lowest pair
+                // fewest iterations first (longest expected remaining chain); among equals the pair
+                // nearest after this workgroup's home index, so that workgroups that look at the
+                // same moment go for different pairs instead of all racing for the lowest one
                 int it = w >> 2;
-                int key = ((it < 2047 ? it : 2047) << 20) | q;
+                int rot = q - home;
+                rot += rot < 0 ? P : 0;
+                int key = ((it < 2047 ? it : 2047) << 20) | rot;
                 best = key < best ? key : best;
             }
         }
@@ -764,7 +982,8 @@ __global__ void __launch_bounds__(TMAX) pair_kernel(const PairBatch pb) {
         if (tid == 0) {
             int pick = -2;  // retry
             if (s_key != 0x7fffffff) {
-                int q = s_key & 0xfffff;
+                int q = (s_key & 0xfffff) + home;
+                q -= q >= P ? P : 0;
                 int w = __hip_atomic_load(&pb.sched_state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((w & 3) <= 1 && atomicCAS(&pb.sched_state[q], w, (w & ~3) | 2) == w) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
