@@ -103,7 +103,7 @@ struct PairGeom {
 };
 
 // does a pair of this size fit the fused kernel?
-bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g) {
+bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool want_matches = true) {
     if (n > kPairMaxN || m > (1 << 20)) return false;
     PairGeom r;
     if (n <= 256) { r.qpt = 1; r.threads = 256; }
@@ -121,7 +121,8 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g) {
     }
     r.tcap = static_cast<int>((m + 3) & ~int64_t(3));  // targets are consumed four at a time
     if (r.tcap < 4) r.tcap = 4;
-    r.scap = (dim == 2 && method == ICPX_TRIMMED) ? next_pow2(static_cast<int>(n)) : 0;
+    // sort area: only the sorted matches of trimmed ICP2 (published through a handle) need it
+    r.scap = (dim == 2 && method == ICPX_TRIMMED && want_matches) ? next_pow2(static_cast<int>(n)) : 0;
     // the packed-f32 candidate filter needs 4 more bytes of LDS per target coordinate; 2D vanilla
     // searches once per begin and never uses it.  Development override: ICPX_FILTER=0
     const char* fe = std::getenv("ICPX_FILTER");
@@ -563,7 +564,7 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
     const int64_t n_total = source_offsets[n_pairs], m_total = target_offsets[n_pairs];
     if ((n_total > 0 && !source) || (m_total > 0 && !target)) return fail(ICPX_ERR_INVALID, "null source/target");
     PairGeom geom;
-    if (!fused_fits(dim, method, n_max, m_max, &geom))
+    if (!fused_fits(dim, method, n_max, m_max, &geom, false))
         return fail(ICPX_ERR_UNSUPPORTED,
                     "icpx_converge_batch: largest pair (%lld x %lld points) exceeds the fused kernel's limits; "
                     "run such pairs through icpx_converge", (long long)n_max, (long long)m_max);

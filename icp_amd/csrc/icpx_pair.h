@@ -522,6 +522,89 @@ ICPX_DEV void bitonic_sort(uint64_t* key, uint32_t* val, int npad, int T) {
     }
 }
 
+// k-th smallest of the (key, point) pairs held QPT per thread, rank 1-based, lexicographic order:
+// MSB-first radix select with 8-bit digits over the 64 key bits (LDS histogram, wave-0 prefix
+// scan), then — only when the rank falls strictly inside a run of equal keys — over the point
+// index.  Replaces the full sort in Trimmed::iterate (trimmed.cpp:55-58): only the threshold is
+// needed to mark the kept matches.  hist: >= 264 ints of LDS.
+template <int QPT>
+ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT], int T, int rank, int* hist,
+                           uint64_t& kth, uint32_t& vth) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    bool act[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; k++) act[k] = valid[k];
+    uint64_t prefix = 0;
+    uint32_t vprefix = 0;
+    int remaining = rank;
+    for (int pass = 0; pass < 10; pass++) {
+        const bool on_key = pass < 8;
+        const int shift = on_key ? 56 - 8 * pass : 8 * (9 - pass);
+        for (int i = tid; i < 256; i += T) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            const uint32_t point = static_cast<uint32_t>(tid + k * T);
+            const int d = on_key ? static_cast<int>((key[k] >> shift) & 255) : static_cast<int>((point >> shift) & 255);
+            // the leading digits of positive doubles of one cloud mostly coincide: one add per wave then
+            const unsigned long long am = __ballot(act[k]);
+            if (am) {
+                const int d0 = __shfl(d, __ffsll(static_cast<long long>(am)) - 1);
+                if (__all(!act[k] || d == d0)) {
+                    if (lane == 0) atomicAdd(&hist[d0], __popcll(am));
+                } else if (act[k]) {
+                    atomicAdd(&hist[d], 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int c[4], s = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                c[u] = hist[4 * lane + u];
+                s += c[u];
+            }
+            int incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int up = __shfl_up(incl, o);
+                incl += lane >= o ? up : 0;
+            }
+            int excl = incl - s;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (excl < remaining && remaining <= excl + c[u]) {
+                    hist[256] = 4 * lane + u;
+                    hist[257] = remaining - excl;
+                    hist[258] = c[u];
+                }
+                excl += c[u];
+            }
+        }
+        __syncthreads();
+        const int d = hist[256];
+        remaining = hist[257];
+        const int bucket = hist[258];
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            const uint32_t point = static_cast<uint32_t>(tid + k * T);
+            const int dk = on_key ? static_cast<int>((key[k] >> shift) & 255) : static_cast<int>((point >> shift) & 255);
+            act[k] = act[k] && dk == d;
+        }
+        if (on_key) prefix |= static_cast<uint64_t>(d) << shift;
+        else vprefix |= static_cast<uint32_t>(d) << shift;
+        if (pass == 7 && remaining == bucket) {
+            // the whole run of equal keys is kept
+            vprefix = 0xffffffffu;
+            break;
+        }
+    }
+    kth = prefix;
+    vth = vprefix;
+    __syncthreads();  // hist may be reused by the caller
+}
+
 // One visit of pair p: optional begin()/setup(), then up to max_steps iterations of the converge
 // loop.  Returns 1 when should_terminate fired (pair finished), 2 when it paused at max_steps.
 template <int D, int METHOD, int QPT>
@@ -766,25 +849,20 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                     have_seed = filter;
 #pragma unroll
                     for (int k = 0; k < QPT; k++) cost[k] = valid[k] ? best[k] : 0.0;
-                    // trimming step, trimmed.cpp:55-58: order by (cost, point), keep the first new_n
-                    const int npad = pb.lds_sort_cap;
-                    for (int i = tid; i < npad; i += T) {
-                        L.skey[i] = ~0ULL;
-                        L.sval[i] = static_cast<uint32_t>(i);
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int k = 0; k < QPT; k++)
-                        if (valid[k]) L.skey[tid + k * T] = static_cast<uint64_t>(__double_as_longlong(cost[k]));
-                    __syncthreads();
-                    bitonic_sort(L.skey, L.sval, npad, T);
+                    // trimming step, trimmed.cpp:55-58: in the order (cost, point) keep the first new_n.
+                    // Only the new_n-th pair is needed to mark them (radix_select); the sorted order
+                    // the reference leaves in `matches` is produced once, at publish time.
                     sorted_matches = true;
                     long long new_n = static_cast<long long>(pb.overlap_rate * static_cast<double>(n));
                     if (new_n < 1) new_n = 1;
                     if (new_n > n) new_n = n;
                     k_sel = static_cast<int>(new_n);
-                    uint64_t kth = L.skey[k_sel - 1];
-                    uint32_t vth = L.sval[k_sel - 1];
+                    uint64_t skeys[QPT];
+#pragma unroll
+                    for (int k = 0; k < QPT; k++) skeys[k] = static_cast<uint64_t>(__double_as_longlong(cost[k]));
+                    uint64_t kth;
+                    uint32_t vth;
+                    radix_select<QPT>(skeys, valid, T, k_sel, reinterpret_cast<int*>(L.gs), kth, vth);
 #pragma unroll
                     for (int k = 0; k < QPT; k++) {
                         uint64_t kk = static_cast<uint64_t>(__double_as_longlong(cost[k]));
@@ -919,11 +997,21 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                     pb.m_cost[s0 + tid + k * T] = cost[k];
                 }
         } else {
-            // Trimmed leaves matches sorted by cost (trimmed.cpp:55-56); LDS still holds the order
+            // Trimmed leaves matches sorted by cost (trimmed.cpp:55-56): sort (cost, point) now
+            const int npad = pb.lds_sort_cap;
+            for (int i = tid; i < npad; i += T) {
+                L.skey[i] = ~0ULL;
+                L.sval[i] = static_cast<uint32_t>(i);
+            }
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < QPT; k++)
-                if (valid[k]) pb.pair_tmp[s0 + tid + k * T] = pair[k];
+                if (valid[k]) {
+                    L.skey[tid + k * T] = static_cast<uint64_t>(__double_as_longlong(cost[k]));
+                    pb.pair_tmp[s0 + tid + k * T] = pair[k];
+                }
             __syncthreads();
+            bitonic_sort(L.skey, L.sval, npad, T);
             for (int r = tid; r < n; r += T) {
                 uint32_t pt = L.sval[r];
                 pb.m_point[s0 + r] = pt;
