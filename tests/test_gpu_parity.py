@@ -293,6 +293,72 @@ def test_trimmed2d_large_path(icp, ob, scans, overlap):
             assert np.array_equal(u, v), name
 
 
+def test_filtered_search_adversarial_inputs(icp, ob):
+    """The f32 candidate filter of the fused kernel must never change a result: exact ties
+    (lattices, duplicated targets), clouds far from the origin (the filter works about the target's
+    bounding-box centre), tiny and huge scales (f32 underflow / the >= 1e18 fall-back to the plain
+    f64 search), and sizes that leave padding in the last block of four."""
+    rng = np.random.default_rng(21)
+    crit = dict(max_iterations=8, transform_tol=(1e-9, 1e-9))
+
+    def clouds(dim, n, m, kind):
+        if kind == "lattice":
+            t = rng.integers(0, 9, (m, dim)).astype(float)
+            s = t[rng.integers(0, m, n)] + 0.5          # every query has many equidistant targets
+        elif kind == "duplicates":
+            base = rng.uniform(-5, 5, (m // 4 + 1, dim))
+            t = np.concatenate([base] * 4)[:m]            # every target four times
+            s = base[rng.integers(0, len(base), n)] + rng.normal(0, 0.05, (n, dim))
+        else:
+            t = rng.uniform(-5, 5, (m, dim))
+            s = t[rng.integers(0, m, n)] + rng.normal(0, 0.05, (n, dim))
+            if kind == "far":
+                t, s = t + 1.0e6, s + 1.0e6
+            elif kind == "far_small":
+                t, s = t * 1e-3 + 12345.678, s * 1e-3 + 12345.678
+            elif kind == "tiny":
+                t, s = t * 1e-25, s * 1e-25
+            elif kind == "huge":
+                t, s = t * 1e19, s * 1e19
+            elif kind == "mixed_scale":
+                t[: m // 2] *= 1e-4
+        return s, t
+
+    for kind in ("lattice", "duplicates", "far", "far_small", "tiny", "huge", "mixed_scale"):
+        for dim, n, m, method in ((2, 777, 1001, "trimmed"), (3, 1300, 1501, "vanilla"), (3, 4096, 4095, "trimmed"),
+                                  (2, 100, 7, "trimmed"), (3, 65, 3, "vanilla")):
+            s, t = clouds(dim, n, m, kind)
+            cls = icp.ICP2 if dim == 2 else icp.ICP3
+            cfg = icp.Config()
+            md = 0.3 * float(np.abs(t).max()) + 1e-30
+            cfg.set("max_distance", md)
+            r = driver(icp, cls, method, crit, cfg).converge(s, t)
+            ro = dev_oracle(ob, dim, method, max_distance=md).converge(
+                s, t, None, ob.make_criteria(**crit))
+            assert r.iteration_count == ro.iteration_count, (kind, dim, n, m, method)
+            assert np.array_equal(r.transform, ro.transform, equal_nan=True), (kind, dim, n, m, method)
+            assert r.cost == ro.cost or (np.isnan(r.cost) and np.isnan(ro.cost)), (kind, dim, n, m, method)
+        # stepwise with matches / neighbours (seeds carried between launches)
+        s, t = clouds(2, 900, 800, kind)
+        x, o = icp.ICP2.from_method("trimmed"), dev_oracle(ob, 2, "trimmed")
+        x.begin(s, t)
+        o.begin(s, t)
+        for it in range(4):
+            x.iterate()
+            o.iterate()
+            for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+                assert np.array_equal(u, v), (kind, it)
+        s, t = clouds(3, 2500, 2600, kind)
+        x, o = icp.ICP3.from_method("vanilla"), dev_oracle(ob, 3, "vanilla")
+        x.begin(s, t)
+        o.begin(s, t)
+        for it in range(3):
+            x.iterate()
+            o.iterate()
+            for u, v in zip(x.debug_neighbors(), o.neighbors()):
+                assert np.array_equal(u, v), (kind, it)
+
+
 def test_driver_criteria_on_device(icp, ob, scans):
     a, b = scans[1]
     for crit in [dict(max_iterations=5), dict(max_iterations=0), dict(min_iterations=7, max_iterations=50, stop_cost=1e9),
