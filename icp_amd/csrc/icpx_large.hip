@@ -18,10 +18,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include <hipcub/hipcub.hpp>
 
+#include "icpx_filter.h"
 #include "icpx_grid.h"
 #include "icpx_large.h"
 #include "icpx_math.h"
@@ -46,6 +49,8 @@ struct LargeDev {
     double ca[3], cb[3];
     double ksel;
     double cost_sum;
+    int nn_valid;  // nb_idx holds the previous correspondence step's neighbours (seeds of the tiled search)
+    int _pad;
 };
 
 struct LargeIcp {
@@ -62,6 +67,10 @@ struct LargeIcp {
     size_t sort_tmp_bytes = 0;
     int64_t new_n = 0;
     bool sorted = false;  // an iterate has run since begin: matches are in sorted order (Q9)
+    // tiled brute-force correspondence (mid-size clouds): (query tiles) x (target splits)
+    bool tile = false;
+    int splits = 0, split_len = 0;
+    DevBuf part_d2, part_idx;
     int* h_done = nullptr;  // pinned
 };
 
@@ -89,6 +98,7 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess) {
     dev->st.start_clock = wall_clock64();
     dev->ksel = 0.0;
     dev->cost_sum = 0.0;
+    dev->nn_valid = 0;
 }
 
 // NN stage.  MODE 0: the 3D per-iteration stage.  MODE 1: Vanilla::setup's compute_matches on the
@@ -137,6 +147,154 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         nb_cost[i] = best;  // trimmed.cpp:101 squaredNorm; selection comes from lg_select_kernel
     } else {
         double c = __builtin_sqrt(__builtin_sqrt(best));  // sqrt of kdtree.h:126's Euclidean distance
+        nb_cost[i] = c;
+        sel[i] = (D == 3 && METHOD == ICPX_TRIMMED) ? (c <= max_distance ? 1 : 0) : 1;
+    }
+}
+
+// ---- tiled brute-force correspondence for mid-size clouds --------------------------------------
+// grid = (query tiles of 1024, target splits).  Each workgroup stages its target split in LDS
+// (f64 SoA + f32 filter copy, icpx_filter.h) and answers its 1024 queries against it: seeded by the
+// previous step's neighbour when there is one (whose exact distance bounds the answer for EVERY
+// split), seedless otherwise.  Per-split results are merged by lg_tile_merge_kernel in the (d2, index)
+// order.  On 256 CUs this beats the grid walk up to about 3e4 x 3e4 points.
+constexpr int kTileThreads = 256;
+constexpr int kTileQpt = 4;
+constexpr int kTileQueries = kTileThreads * kTileQpt;
+constexpr int kTileScratch = 96;  // doubles of reduction scratch
+constexpr int kTileMaxSplit = 3072;  // targets per split at most (3D: 110 KB of LDS)
+constexpr int kTileMinSplit = 512;
+constexpr int64_t kTileMaxWork = int64_t(1) << 30;  // n*m up to which ICPX_NN_AUTO prefers the tiled search
+
+inline size_t tile_lds_bytes(int dim, int scap) {
+    return sizeof(double) * (static_cast<size_t>(dim) * scap + kTileScratch) + sizeof(float) * static_cast<size_t>(dim) * scap;
+}
+
+template <int D>
+__global__ void lg_step_kernel(LargeDev* dev, int respect_done, double* __restrict__ cur, int64_t n) {
+    if (respect_done && dev->st.done) return;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // c = T * c with the step the previous iteration produced (identity after begin), vanilla_3d.cpp:91
+    Xf<D> S;
+#pragma unroll
+    for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
+    XfRows<D> sr = xf_rows<D>(S);
+    double c[D], q[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
+    xf_apply<D>(sr, c, q);
+#pragma unroll
+    for (int d = 0; d < D; d++) cur[i * D + d] = q[d];
+}
+
+// MODE as in lg_nn_kernel (0: queries = running cloud, already stepped; 1: untransformed source;
+// 2: transform * source)
+template <int D, int MODE>
+__global__ void __launch_bounds__(kTileThreads)
+lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
+                  int64_t n, const double* __restrict__ dst, int64_t m, int split_len, int scap,
+                  const int64_t* __restrict__ nb_idx, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
+    extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+    if (respect_done && dev->st.done) return;
+    const int tid = threadIdx.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
+    const int mt = static_cast<int>(m - t0 < split_len ? m - t0 : split_len);
+    const int m4 = (mt + 3) & ~3;
+    LdsView<D> L;
+    double* p = tile_lds;
+    for (int d = 0; d < 3; d++) {
+        L.t[d] = d < D ? p : nullptr;
+        if (d < D) p += scap;
+    }
+    L.gs = p;
+    p += kTileScratch;
+    L.bc = nullptr;
+    L.skey = nullptr;
+    L.sval = nullptr;
+    float* f = reinterpret_cast<float*>(p);
+    for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
+    L.j0 = static_cast<int>(t0);
+    const FilterFrame F = stage_targets<D>(dst + t0 * D, mt, m4, kTileThreads, L, true);
+
+    double q[kTileQpt][D], best[kTileQpt];
+    int bidx[kTileQpt];
+    const int64_t qbase = static_cast<int64_t>(blockIdx.x) * kTileQueries;
+    const bool seeded = dev->nn_valid != 0;
+    XfRows<D> xr;
+    if (MODE == 2) {
+        Xf<D> X;
+#pragma unroll
+        for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+        xr = xf_rows<D>(X);
+    }
+#pragma unroll
+    for (int k = 0; k < kTileQpt; k++) {
+        const int64_t i = qbase + tid + k * kTileThreads;
+        const bool valid = i < n;
+        double pnt[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) pnt[d] = valid ? (MODE == 0 ? cur[i * D + d] : src[i * D + d]) : 0.0;
+        if (MODE == 2) {
+            xf_apply<D>(xr, pnt, q[k]);  // a_current = transform * a, trimmed.cpp:40
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; d++) q[k][d] = pnt[d];
+        }
+        best[k] = __builtin_inf();
+        bidx[k] = 0x7fffffff;
+        if (seeded) {
+            // exact distance to the previous neighbour: an upper bound for every split
+            int64_t j = valid ? nb_idx[i] : 0;
+            j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+            double df = dst[j * D + 0] - q[k][0];
+            double acc = df * df;
+#pragma unroll
+            for (int d = 1; d < D; d++) {
+                df = dst[j * D + d] - q[k][d];
+                acc = acc + df * df;
+            }
+            best[k] = acc;
+            bidx[k] = static_cast<int>(j);
+        }
+    }
+    if (seeded) nn_filtered<D, kTileQpt>(q, L, m4, F, best, bidx);
+    else nn_twomin<D, kTileQpt>(q, L, m4, F, best, bidx);
+#pragma unroll
+    for (int k = 0; k < kTileQpt; k++) {
+        const int64_t i = qbase + tid + k * kTileThreads;
+        if (i < n) {
+            part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = best[k];
+            part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = bidx[k];
+        }
+    }
+}
+
+// (d2, index) minimum over the splits, then the epilogue of lg_nn_kernel
+template <int D, int METHOD, int MODE>
+__global__ void __launch_bounds__(256)
+lg_tile_merge_kernel(LargeDev* dev, int respect_done, int64_t n, int splits, const double* __restrict__ part_d2,
+                     const int32_t* __restrict__ part_idx, int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost,
+                     uint8_t* __restrict__ sel, double max_distance) {
+    if (respect_done && dev->st.done) return;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i == 0) dev->nn_valid = 1;
+    if (i >= n) return;
+    double best = part_d2[i];
+    int32_t bi = part_idx[i];
+    for (int s = 1; s < splits; s++) {
+        double d = part_d2[static_cast<int64_t>(s) * n + i];
+        int32_t j = part_idx[static_cast<int64_t>(s) * n + i];
+        bool take = d < best || (d == best && j < bi);
+        best = take ? d : best;
+        bi = take ? j : bi;
+    }
+    if (bi == 0x7fffffff) bi = 0;  // nothing finite anywhere (non-finite input): the reference's untouched index
+    nb_idx[i] = bi;
+    if (MODE == 2) {
+        nb_cost[i] = best;
+    } else {
+        double c = __builtin_sqrt(__builtin_sqrt(best));
         nb_cost[i] = c;
         sel[i] = (D == 3 && METHOD == ICPX_TRIMMED) ? (c <= max_distance ? 1 : 0) : 1;
     }
@@ -597,7 +755,8 @@ void large_destroy(LargeIcp* lg) {
     if (!lg) return;
     (void)hipStreamSynchronize(lg->stream);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
-                      &lg->cntp, &lg->dev, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp})
+                      &lg->cntp, &lg->dev, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
+                      &lg->part_d2, &lg->part_idx})
         b->release();
     grid_destroy(lg->grid);
     if (lg->h_done) (void)hipHostFree(lg->h_done);
@@ -628,19 +787,56 @@ int enqueue_sums(LargeIcp* lg, int respect_done, bool second) {
     return ICPX_OK;
 }
 
+// the correspondence stage of one step: the tiled brute force (mid-size clouds) or the grid walk
+template <int D, int METHOD, int MODE>
+int enqueue_nn(LargeIcp* lg, int respect) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+    if (!lg->tile) {
+        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect,
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
+                           lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
+                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+        ICPX_HIP(hipGetLastError());
+        return ICPX_OK;
+    }
+    if (MODE == 0) {
+        hipLaunchKernelGGL(lg_step_kernel<D>, dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->cur.as<double>(), lg->n);
+        ICPX_HIP(hipGetLastError());
+    }
+    auto kern = lg_tile_nn_kernel<D, MODE>;
+    const size_t lds = tile_lds_bytes(D, lg->split_len);
+    static std::mutex mu;
+    static std::unordered_map<int, bool> attr_set;
+    {
+        int devid = 0;
+        ICPX_HIP(hipGetDevice(&devid));
+        std::lock_guard<std::mutex> lk(mu);
+        if (!attr_set[devid]) {
+            ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(tile_lds_bytes(3, kTileMaxSplit))));
+            attr_set[devid] = true;
+        }
+    }
+    dim3 grid(static_cast<unsigned>((lg->n + kTileQueries - 1) / kTileQueries), static_cast<unsigned>(lg->splits));
+    hipLaunchKernelGGL(kern, grid, dim3(kTileThreads), lds, lg->stream, dev, respect, lg->src.as<double>(),
+                       lg->cur.as<double>(), lg->n, lg->dst.as<double>(), lg->m, lg->split_len, lg->split_len,
+                       lg->nb_idx.as<int64_t>(), lg->part_d2.as<double>(), lg->part_idx.as<int32_t>());
+    ICPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL((lg_tile_merge_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n,
+                       lg->splits, lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->nb_idx.as<int64_t>(),
+                       lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
 template <int D, int METHOD>
 int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
     LargeDev* dev = lg->dev.as<LargeDev>();
     hipLaunchKernelGGL(lg_init_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->guess.as<double>());
     ICPX_HIP(hipGetLastError());
     if (D == 2) {
-        unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
-        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, METHOD == ICPX_TRIMMED ? 2 : 1>), dim3(nb), dim3(256), 0,
-                           lg->stream, dev, 0,
-                           lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
-                           lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
-                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
-        ICPX_HIP(hipGetLastError());
+        ICPX_TRY((enqueue_nn<D, METHOD, METHOD == ICPX_TRIMMED ? 2 : 1>(lg, 0)));
         ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
     }
     hipLaunchKernelGGL(lg_setup_finish_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, check, crit,
@@ -653,14 +849,7 @@ template <int D, int METHOD>
 int enqueue_iteration(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
     LargeDev* dev = lg->dev.as<LargeDev>();
     const int respect = check;
-    if (D == 3 || METHOD == ICPX_TRIMMED) {
-        unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
-        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, D == 3 ? 0 : 2>), dim3(nb), dim3(256), 0, lg->stream, dev,
-                           respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
-                           lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
-                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
-        ICPX_HIP(hipGetLastError());
-    }
+    if (D == 3 || METHOD == ICPX_TRIMMED) ICPX_TRY((enqueue_nn<D, METHOD, D == 3 ? 0 : 2>(lg, respect)));
     if (D == 2 && METHOD == ICPX_TRIMMED) {
         // std::sort by cost (trimmed.cpp:55-56) made total: a stable LSD radix sort over the
         // cost's bit pattern (costs are >= 0, so bit order is numeric order) with the point index
@@ -742,7 +931,27 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
                            lg->sort_iota.as<uint32_t>());
         ICPX_HIP(hipGetLastError());
     }
-    ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
+    // correspondence engine: tiled brute force for mid-size clouds, the uniform grid beyond
+    // (ICPX_NN_GRID / ICPX_NN_BRUTE force one or the other)
+    lg->tile = lg->prm.nn_mode == ICPX_NN_BRUTE ||
+               (lg->prm.nn_mode != ICPX_NN_GRID && static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
+    if (lg->tile) {
+        const int64_t ntq = (n + kTileQueries - 1) / kTileQueries;
+        int64_t splits = (768 + ntq - 1) / ntq;                       // aim at ~3 workgroups per CU
+        const int64_t most = (m + kTileMinSplit - 1) / kTileMinSplit;  // splits of at least kTileMinSplit targets
+        if (splits > most) splits = most;
+        if (splits < 1) splits = 1;
+        int64_t len = ((m + splits - 1) / splits + 3) & ~int64_t(3);
+        if (len > kTileMaxSplit) len = kTileMaxSplit;
+        splits = (m + len - 1) / len;
+        if (splits > 65535) return fail(ICPX_ERR_UNSUPPORTED, "target cloud too large for the tiled search; use nn = grid");
+        lg->splits = static_cast<int>(splits);
+        lg->split_len = static_cast<int>(len);
+        ICPX_TRY(lg->part_d2.reserve(sizeof(double) * static_cast<size_t>(splits) * n));
+        ICPX_TRY(lg->part_idx.reserve(sizeof(int32_t) * static_cast<size_t>(splits) * n));
+    } else {
+        ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
+    }
     return LG_DISPATCH(enqueue_setup, lg, 0, zero_criteria(), 0.0);
 }
 

@@ -14,6 +14,7 @@
 // fits LDS (checked on the host, icpx_capi.hip).  Larger clouds take the multi-kernel path.
 #pragma once
 
+#include "icpx_filter.h"
 #include "icpx_math.h"
 
 namespace icpx {
@@ -59,16 +60,6 @@ struct PairBatch {
     int32_t* seeds;            // n_total: previous nearest neighbour by point, carried between launches / tasks; may be nullptr
 };
 
-template <int D>
-struct LdsView {
-    double* t[3];    // target SoA
-    double* gs;      // kGsValues x kGsStride
-    double* bc;      // broadcast
-    uint64_t* skey;  // sort keys
-    uint32_t* sval;  // sort values
-    float* tf[3];    // f32 copy of the target SoA (candidate filter), null when not reserved
-};
-
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
     size_t b = sizeof(double) * (static_cast<size_t>(dim) * tcap + kGsValues * kGsStride + kBcDoubles) +
                static_cast<size_t>(scap) * 12;
@@ -92,361 +83,12 @@ ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap, int filter) {
     v.sval = reinterpret_cast<uint32_t*>(v.skey + scap);
     float* f = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + pair_lds_filter_offset(D, tcap, scap));
     for (int d = 0; d < 3; d++) v.tf[d] = (filter && d < D) ? f + static_cast<size_t>(d) * tcap : nullptr;
+    v.j0 = 0;
     return v;
 }
 
 inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter) {
     return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0);
-}
-
-// brute-force NN of QPT register-resident queries against the LDS target cloud.
-// d2 = ((dx*dx) + dy*dy) + dz*dz with dx = target - query (trimmed.cpp:101), strict <,
-// ascending j  =>  lexicographic min of (d2, j).
-//
-// Targets are taken four at a time: the block minimum (v_min_f64 tree) is compared with the
-// running best by strict <, so `bblk` ends as the FIRST block that attains the global minimum —
-// exactly the block the one-by-one loop of the reference would have stopped improving in.  The
-// index inside that block is resolved afterwards by recomputing its four distances (same
-// operations, same bits) and taking the lowest j that equals the minimum.  This costs 9.5 (3D) /
-// 6.5 (2D) VALU instructions per pair instead of 12 / 9 with a per-target compare-and-select.
-// `m4` is m rounded up to a multiple of 4; LDS slots [m, m4) hold +inf (never selected).
-template <int D, int QPT>
-ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, double (&best)[QPT],
-                     int (&bidx)[QPT]) {
-    int bblk[QPT];
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        best[k] = __builtin_inf();
-        bblk[k] = 0;
-    }
-    for (int jb = 0; jb < m4; jb += 4) {
-        double tc[D][4];
-#pragma unroll
-        for (int d = 0; d < D; d++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) tc[d][u] = L.t[d][jb + u];
-#pragma unroll
-        for (int k = 0; k < QPT; k++) {
-            double dist[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                double df = tc[0][u] - q[k][0];
-                double acc = df * df;
-#pragma unroll
-                for (int d = 1; d < D; d++) {
-                    df = tc[d][u] - q[k][d];
-                    acc = acc + df * df;
-                }
-                dist[u] = acc;
-            }
-            double mm = __builtin_fmin(__builtin_fmin(dist[0], dist[1]), __builtin_fmin(dist[2], dist[3]));
-            bool lt = mm < best[k];
-            best[k] = __builtin_fmin(best[k], mm);
-            bblk[k] = lt ? jb : bblk[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        int idx = 0;
-        if (best[k] < __builtin_inf()) {
-#pragma unroll
-            for (int u = 3; u >= 0; u--) {
-                double df = L.t[0][bblk[k] + u] - q[k][0];
-                double acc = df * df;
-#pragma unroll
-                for (int d = 1; d < D; d++) {
-                    df = L.t[d][bblk[k] + u] - q[k][d];
-                    acc = acc + df * df;
-                }
-                idx = acc == best[k] ? bblk[k] + u : idx;
-            }
-        }
-        bidx[k] = idx;
-    }
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// development statistics (build with -DICPX_STATS; read with icpx_debug_stats):
-//   0 seeded scans (wave)  1 exact flushes (wave)  2 two-min scans (wave)  3 near-tie lanes  4 slot rescans (wave)
-#ifdef ICPX_STATS
-__device__ unsigned long long g_icpx_stats[8];
-#define ICPX_STAT(slot_, amount_)                                                                    \
-    do {                                                                                             \
-        unsigned long long stat_v_ = (unsigned long long)(amount_);                                  \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_icpx_stats[slot_], stat_v_);                       \
-    } while (0)
-#else
-#define ICPX_STAT(slot_, amount_) do { } while (0)
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// f32 candidate filter in front of the exact f64 search.
-//
-// Measured on MI355X (tools/micro/rate_probe.hip): a wave64 v_fma_f64 / v_add_f64 / v_pk_*_f32
-// issues every ~5 cycles per SIMD, a plain v_fma_f32 / v_min_f32 every ~2.8.  The exact search
-// costs ~10 f64 instructions per (query, target); the filter below costs 3 plain f32 FMAs.
-//
-// Filter value of target j for query q (both moved by the same offset c0, the centre of the
-// target's bounding box, then rounded to f32: t32, q32):
-//     v_j = |t32_j|^2 - 2 t32_j . q32          ( = |t32_j - q32|^2 - |q32|^2 )
-// computed as fma(tz, -2qz, fma(ty, -2qy, fma(tx, -2qx, |t32|^2))), |t32|^2 once per target and wave.
-// Error budget, u = 2^-24, Mt / Mq = max |coordinate| of the moved targets / of the moved query:
-//   * rounding the moved coordinates to f32 displaces t32 - q32 from the true difference vector
-//     by at most sqrt(D) u (Mt + Mq) <= E = 2^-22 (Mt + Mq)                 (distance domain)
-//   * the f32 arithmetic of v_j is off by at most 6 u (|t32| + |q32|)^2 <= E2 = 24 u (Mt + Mq)^2
-// so every target with exact distance d_j <= B satisfies  v_j <= (B + E)^2 - |q32|^2 + E2.
-// filter_threshold returns an upper bound of that right-hand side for B^2 = d2max; a block of
-// four targets whose smallest v is above it cannot contain a target with d2 <= d2max — ties
-// included — whatever the rounding did.  Candidate blocks are re-evaluated exactly (exact_block),
-// with the reference's expression on the original coordinates and the (d2, j) rule, so the result
-// is the one nn_lds gives, bit for bit.
-// ---------------------------------------------------------------------------------------------
-struct FilterFrame {
-    double c0[3];      // common offset: centre of the target bounding box
-    double t_absmax;   // max |t - c0| over the target cloud; +inf when a coordinate is not finite / >= 1e18
-};
-
-ICPX_DEV float filter_threshold(double d2max, float qn_lo, float e_dist, float e_val) {
-    float d2f = static_cast<float>(d2max) * 1.0000005f + 1e-30f;   // >= d2max
-    float s = __builtin_sqrtf(d2f) * 1.000002f + e_dist;           // >= sqrt(d2max) + E
-    float a = s * s * 1.000004f;                                    // >= (B + E)^2
-    return (a - qn_lo) + (e_val + (a + qn_lo) * 2.4e-7f + 1e-30f);  // f32 roundings of this line: <= 2^-22 (a + qn)
-}
-
-// exact (d2, j) update of one query against the four targets of block `blk` (lanes with blk < 0 idle)
-template <int D>
-ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, double& best, int& bidx) {
-    const bool act = blk >= 0;
-    const int jb = act ? blk : 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        double df = L.t[0][jb + u] - q[0];
-        double acc = df * df;
-#pragma unroll
-        for (int d = 1; d < D; d++) {
-            df = L.t[d][jb + u] - q[d];
-            acc = acc + df * df;
-        }
-        bool better = act && (acc < best || (acc == best && jb + u < bidx));
-        best = better ? acc : best;
-        bidx = better ? jb + u : bidx;
-    }
-}
-
-// per-lane filter operands of the QPT queries; returns false when this lane cannot use the filter
-template <int D, int QPT>
-ICPX_DEV bool filter_queries(const double (&q)[QPT][D], const FilterFrame& F, float (&q2)[QPT][D], float (&qn)[QPT],
-                             float& e_dist, float& e_val) {
-    bool ok = F.t_absmax < 1e18;
-    double mq = 0.0;
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        double nn = 0.0;
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            double c = q[k][d] - F.c0[d];
-            ok = ok && (__builtin_fabs(c) < 1e18);
-            mq = __builtin_fmax(mq, __builtin_fabs(c));
-            float f = static_cast<float>(c);
-            q2[k][d] = -2.0f * f;
-            nn = nn + static_cast<double>(f) * static_cast<double>(f);
-        }
-        qn[k] = static_cast<float>(nn * (1.0 - 1.0 / 4194304.0));  // <= |q32|^2
-    }
-    const double mm = F.t_absmax + mq;
-    e_dist = static_cast<float>(mm * (1.001 / 4194304.0));           // 2^-22 (Mt + Mq)
-    e_val = static_cast<float>(mm * mm * (24.3 / 16777216.0));       // 24 u (Mt + Mq)^2
-    return ok;
-}
-
-// smallest filter value of the four targets of a block for one query
-template <int D>
-ICPX_DEV float block_filter_min(const f32x4 (&tc)[D], const f32x4& tn, const float (&q2)[D]) {
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        float a = __builtin_fmaf(tc[0][u], q2[0], tn[u]);
-#pragma unroll
-        for (int d = 1; d < D; d++) a = __builtin_fmaf(tc[d][u], q2[d], a);
-        v[u] = a;
-    }
-    return __builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3]));
-}
-
-template <int D>
-ICPX_DEV void load_filter_block(const LdsView<D>& L, int jb, f32x4 (&tc)[D], f32x4& tn) {
-#pragma unroll
-    for (int d = 0; d < D; d++) tc[d] = *reinterpret_cast<const f32x4*>(L.tf[d] + jb);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        float a = tc[0][u] * tc[0][u];
-#pragma unroll
-        for (int d = 1; d < D; d++) a = __builtin_fmaf(tc[d][u], tc[d][u], a);
-        tn[u] = a;
-    }
-}
-
-// Seeded search: bidx holds the previous iteration's neighbours.  The exact distance to the seed
-// bounds the answer; ALL targets are scanned through the filter, four at a time; candidate
-// blocks are evaluated exactly and every improvement tightens the threshold.  One pending block
-// per query slot is kept in a register; a second candidate for the same slot flushes the first
-// (wave-wide).  Waves with unusable coordinates take nn_lds.
-template <int D, int QPT>
-ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m, int m4, const FilterFrame& F,
-                          double (&best)[QPT], int (&bidx)[QPT]) {
-    float q2[QPT][D], qn[QPT], e_dist, e_val;
-    const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
-    if (__any(!ok)) {
-        nn_lds<D, QPT>(q, L, m4, best, bidx);
-        return;
-    }
-    float thr[QPT];
-    int pend[QPT];
-    ICPX_STAT(0, 1);
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        int j = bidx[k];
-        j = j < 0 ? 0 : (j >= m ? m - 1 : j);
-        double df = L.t[0][j] - q[k][0];
-        double acc = df * df;
-#pragma unroll
-        for (int d = 1; d < D; d++) {
-            df = L.t[d][j] - q[k][d];
-            acc = acc + df * df;
-        }
-        best[k] = acc;
-        bidx[k] = j;
-        thr[k] = filter_threshold(acc, qn[k], e_dist, e_val);
-        pend[k] = -1;
-    }
-    constexpr int G = QPT >= 2 ? 2 : 1;  // slots per branch: wider basic blocks schedule better
-    for (int jb = 0; jb < m4; jb += 4) {
-        f32x4 tc[D], tn;
-        load_filter_block<D>(L, jb, tc, tn);
-#pragma unroll
-        for (int k0 = 0; k0 < QPT; k0 += G) {
-            bool cand[G];
-            bool any = false;
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-                cand[g] = !(block_filter_min<D>(tc, tn, q2[k0 + g]) > thr[k0 + g]);
-                any = any || cand[g];
-            }
-            if (__any(any)) {
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    const int k = k0 + g;
-                    if (__any(cand[g] && pend[k] >= 0)) {
-                        ICPX_STAT(1, 1);
-                        double before = best[k];
-                        exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
-                        pend[k] = -1;
-                        if (best[k] < before) thr[k] = filter_threshold(best[k], qn[k], e_dist, e_val);
-                    }
-                    pend[k] = cand[g] ? jb : pend[k];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < QPT; k++)
-        if (__any(pend[k] >= 0)) exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
-}
-
-// Wave-cooperative rescan of single queries: for every lane whose flag is set, the wave takes
-// that lane's query (broadcast), each lane filters the blocks lane, lane + 64, ... and evaluates
-// its candidate blocks exactly; a butterfly over (d2, j) leaves the lexicographic minimum, which
-// the owning lane keeps.  1024 blocks cost 16 steps instead of a 1024-step scan with one useful
-// lane.
-template <int D>
-ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D], float thr, const LdsView<D>& L,
-                          int m4, double& best, int& bidx) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long mask = __ballot(flag);
-    while (mask) {
-        const int src = __ffsll(static_cast<long long>(mask)) - 1;
-        mask &= mask - 1;
-        double qb[D];
-        float q2b[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            qb[d] = __shfl(q[d], src);
-            q2b[d] = __shfl(q2[d], src);
-        }
-        const float thr_b = __shfl(thr, src);
-        double bb = __builtin_inf();
-        int bi = 0x7fffffff;
-        for (int jb = lane * 4; jb < m4; jb += 256) {
-            f32x4 tc[D], tn;
-            load_filter_block<D>(L, jb, tc, tn);
-            if (!(block_filter_min<D>(tc, tn, q2b) > thr_b)) exact_block<D>(qb, L, jb, bb, bi);
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            double ob = __shfl_xor(bb, o);
-            int oi = __shfl_xor(bi, o);
-            bool take = ob < bb || (ob == bb && oi < bi);
-            bb = take ? ob : bb;
-            bi = take ? oi : bi;
-        }
-        if (lane == src && bb < __builtin_inf()) {
-            best = bb;
-            bidx = bi;
-        }
-    }
-}
-
-// Seedless search (first search of a pair): ONE filter pass keeps, per query, the smallest
-// block value b1 with its block and the second smallest b2 over all other blocks:
-//     b2' = min(b2, max(b1, v)),  b1' = min(b1, v).
-// The winning block is evaluated exactly; if b2 lies above the threshold of that exact best, no
-// other block can hold a target with d2 <= best and the search is complete.  Otherwise — exact
-// ties and near-ties inside the error budget — the query is rescanned cooperatively (coop_rescan).
-template <int D, int QPT>
-ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m, int m4, const FilterFrame& F,
-                        double (&best)[QPT], int (&bidx)[QPT]) {
-    float q2[QPT][D], qn[QPT], e_dist, e_val;
-    const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
-    if (__any(!ok)) {
-        nn_lds<D, QPT>(q, L, m4, best, bidx);
-        return;
-    }
-    float b1[QPT], b2[QPT];
-    int blk[QPT];
-    ICPX_STAT(2, 1);
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        b1[k] = __builtin_inff();
-        b2[k] = __builtin_inff();
-        blk[k] = 0;
-    }
-    for (int jb = 0; jb < m4; jb += 4) {
-        f32x4 tc[D], tn;
-        load_filter_block<D>(L, jb, tc, tn);
-#pragma unroll
-        for (int k = 0; k < QPT; k++) {
-            float mn = block_filter_min<D>(tc, tn, q2[k]);
-            bool lt = mn < b1[k];
-            b2[k] = __builtin_fminf(b2[k], __builtin_fmaxf(b1[k], mn));
-            b1[k] = __builtin_fminf(b1[k], mn);
-            blk[k] = lt ? jb : blk[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        best[k] = __builtin_inf();
-        bidx[k] = 0;
-        exact_block<D>(q[k], L, blk[k], best[k], bidx[k]);
-        // near-ties (about 0.15 % of the queries on uniform clouds): cooperative rescan
-        const float thr = filter_threshold(best[k], qn[k], e_dist, e_val);
-        const bool again = !(b2[k] > thr);
-        ICPX_STAT(3, __popcll(__ballot(again)));
-        if (__any(again)) {
-            ICPX_STAT(4, 1);
-            coop_rescan<D>(again, q[k], q2[k], thr, L, m4, best[k], bidx[k]);
-        }
-    }
 }
 
 // TREE64 sum of NV values per point.  f(k, vals) fills the NV contributions of point tid + k*T
@@ -624,81 +266,10 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
     const bool empty = (n == 0 || m == 0);
 
-    // ---- stage the target cloud into LDS as SoA ----
+    // ---- stage the target cloud into LDS as SoA (+ f32 copy about the bounding-box centre) ----
     const int m4 = (m + 3) & ~3;
-    double lo[D], hi[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        lo[d] = __builtin_inf();
-        hi[d] = -__builtin_inf();
-    }
-    bool t_bad = false;
-    for (int j = tid; j < m4; j += T) {
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            double v = j < m ? dst[static_cast<int64_t>(j) * D + d] : __builtin_inf();
-            L.t[d][j] = v;
-            if (filter && j < m) {
-                t_bad = t_bad || !(__builtin_fabs(v) < 1e300);
-                lo[d] = __builtin_fmin(lo[d], v);
-                hi[d] = __builtin_fmax(hi[d], v);
-            }
-        }
-    }
-    // filter frame: bounding-box centre, f32 copy of the moved targets, max |moved coordinate|
-    FilterFrame F;
-#pragma unroll
-    for (int d = 0; d < 3; d++) F.c0[d] = 0.0;
-    F.t_absmax = __builtin_inf();
-    if (filter) {
-        const int lane = tid & 63, wave = tid >> 6, W = T >> 6;
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                lo[d] = __builtin_fmin(lo[d], __shfl_xor(lo[d], o));
-                hi[d] = __builtin_fmax(hi[d], __shfl_xor(hi[d], o));
-            }
-            if (lane == 0) {
-                L.gs[wave * 8 + d] = lo[d];
-                L.gs[wave * 8 + 4 + d] = hi[d];
-            }
-        }
-        const bool wave_bad = __any(t_bad);
-        if (lane == 0) L.gs[wave * 8 + 3] = wave_bad ? 1.0 : 0.0;
-        __syncthreads();
-        bool any_bad = false;
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            double l = __builtin_inf(), h = -__builtin_inf();
-            for (int w = 0; w < W; w++) {
-                l = __builtin_fmin(l, L.gs[w * 8 + d]);
-                h = __builtin_fmax(h, L.gs[w * 8 + 4 + d]);
-            }
-            F.c0[d] = m > 0 ? 0.5 * l + 0.5 * h : 0.0;
-        }
-        for (int w = 0; w < W; w++) any_bad = any_bad || L.gs[w * 8 + 3] != 0.0;
-        double amax = 0.0;
-        for (int j = tid; j < m4; j += T) {
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                double c = L.t[d][j] - F.c0[d];
-                bool real = j < m;
-                // padding: a large finite value, never a candidate and never NaN in the filter
-                L.tf[d][j] = real ? static_cast<float>(c) : 1e18f;
-                if (real) amax = __builtin_fmax(amax, __builtin_fabs(c) < 1e18 ? __builtin_fabs(c) : __builtin_inf());
-            }
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) amax = __builtin_fmax(amax, __shfl_xor(amax, o));
-        __syncthreads();  // everyone has read the bounding box before gs is reused
-        if (lane == 0) L.gs[wave] = amax;
-        __syncthreads();
-        amax = 0.0;
-        for (int w = 0; w < W; w++) amax = __builtin_fmax(amax, L.gs[w]);
-        F.t_absmax = any_bad ? __builtin_inf() : amax;
-        // the barrier after the state block below separates these reads from the next use of gs
-    }
+    const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter);
+
     // ---- per-thread point slots ----
     double a[QPT][D];    // 2D: source points; 3D: running cloud c
     double cost[QPT];    // match cost (2D) / neighbour distance (3D)
@@ -773,7 +344,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            if (filter) nn_twomin<D, QPT>(q, L, m, m4, F, best, pair);
+            if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
             else nn_lds<D, QPT>(q, L, m4, best, pair);
             have_seed = filter;
 #pragma unroll
@@ -843,8 +414,10 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
-                    if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, F, best, pair);
-                    else if (filter) nn_twomin<D, QPT>(cur, L, m, m4, F, best, pair);
+                    if (have_seed) {
+                        seed_bound<D, QPT>(cur, L, m, best, pair);
+                        nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
+                    } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
                     else nn_lds<D, QPT>(cur, L, m4, best, pair);
                     have_seed = filter;
 #pragma unroll
@@ -880,8 +453,10 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 double best[QPT];
-                if (have_seed) nn_filtered<D, QPT>(cur, L, m, m4, F, best, pair);
-                else if (filter) nn_twomin<D, QPT>(cur, L, m, m4, F, best, pair);
+                if (have_seed) {
+                    seed_bound<D, QPT>(cur, L, m, best, pair);
+                    nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
+                } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
                 else nn_lds<D, QPT>(cur, L, m4, best, pair);
                 have_seed = filter;
 #pragma unroll

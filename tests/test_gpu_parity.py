@@ -145,11 +145,15 @@ def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k):
     assert abs(rs.cost - r.cost) < 1e-12
 
 
+@pytest.mark.parametrize("nn", ["auto", "grid"])
 @pytest.mark.parametrize("method", ["vanilla", "trimmed"])
-def test_queen_large_path(icp, ob, queen, traces, method):
-    """BASELINE config 3 (10 720 points): grid NN + multi-kernel reductions."""
+def test_queen_large_path(icp, ob, queen, traces, method, nn):
+    """BASELINE config 3 (10 720 points) on the multi-kernel path: tiled brute-force NN (auto at this
+    size) and the uniform-grid NN (forced), multi-kernel reductions."""
     src, dst = queen
-    d = driver(icp, icp.ICP3, method, PLY_CRIT)
+    cfg = icp.Config()
+    cfg.set("nn", nn)
+    d = driver(icp, icp.ICP3, method, PLY_CRIT, cfg)
     r = d.converge(src, dst)
     g = traces[f"queen/{method}/dev"]
     assert r.iteration_count == g["iterations"] == 12
@@ -291,6 +295,46 @@ def test_trimmed2d_large_path(icp, ob, scans, overlap):
         assert np.array_equal(r.transform, ro.transform) and r.cost == ro.cost, name
         for u, v in zip(d.icp_.get_matches_arrays(), o.get_matches()):
             assert np.array_equal(u, v), name
+
+
+@pytest.mark.parametrize("nn", ["auto", "grid"])
+def test_large_path_sizes_and_engines(icp, ob, nn):
+    """Clouds beyond the fused kernel (n > 4096 or target not in LDS), all four methods, both
+    correspondence engines of the multi-kernel path; ragged sizes around the tile / split limits."""
+    from icp_amd import synth
+    crit = dict(max_iterations=6, transform_tol=(1e-7, 1e-7))
+    for dim, n, m in ((2, 5000, 4100), (2, 4097, 9000), (3, 4500, 1023), (3, 1030, 7001), (3, 9000, 9001)):
+        s, t, _, _ = synth.config5_pairs([n + m], dim, max(n, m))
+        s, t = s[:n], t[:m]
+        for method in ("vanilla", "trimmed"):
+            cfg = icp.Config()
+            cfg.set("nn", nn)
+            cfg.set("max_distance", 0.35)
+            cls = icp.ICP2 if dim == 2 else icp.ICP3
+            if nn == "auto" and n <= 4096 and m < 4000:
+                continue  # would take the fused kernel
+            d = driver(icp, cls, method, crit, cfg)
+            r = d.converge(s, t)
+            o = dev_oracle(ob, dim, method, max_distance=0.35)
+            ro = o.converge(s, t, None, ob.make_criteria(**crit))
+            assert r.iteration_count == ro.iteration_count, (dim, n, m, method)
+            assert np.array_equal(r.transform, ro.transform), (dim, n, m, method)
+            assert r.cost == ro.cost, (dim, n, m, method)
+            if dim == 3:
+                for u, v in zip(d.icp_.debug_neighbors(), o.neighbors()):
+                    assert np.array_equal(u, v), (dim, n, m, method)
+            else:
+                for u, v in zip(d.icp_.get_matches_arrays(), o.get_matches()):
+                    assert np.array_equal(u, v), (dim, n, m, method)
+    # exact ties and far-from-origin data through the tiled search
+    rng = np.random.default_rng(5)
+    lat = rng.integers(0, 30, (6000, 3)).astype(float)
+    for s, t in ((lat[:5000] + 0.5, lat), (lat[:5000] * 1e-3 + 7.0e5, lat * 1e-3 + 7.0e5 + 1e-4)):
+        cfg = icp.Config()
+        cfg.set("nn", nn)
+        r = driver(icp, icp.ICP3, "vanilla", crit, cfg).converge(s, t)
+        ro = dev_oracle(ob, 3, "vanilla").converge(s, t, None, ob.make_criteria(**crit))
+        assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
 
 
 def test_filtered_search_adversarial_inputs(icp, ob):
