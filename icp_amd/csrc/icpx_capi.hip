@@ -96,6 +96,8 @@ int next_pow2(int v) {
     return p;
 }
 
+constexpr double kFusedSingleMaxWork = 1.1e6;  // measured crossover (n = m = 1024), see DESIGN.md 4.4
+
 struct PairGeom {
     int qpt, threads, tcap, scap;
     bool filter;  // f32 target copy reserved in LDS (nn_filtered)
@@ -308,7 +310,13 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
         return fail(ICPX_ERR_INVALID, "null source/target/guess");
     if (n > INT32_MAX / 4 || m > INT32_MAX / 4) return fail(ICPX_ERR_UNSUPPORTED, "cloud too large");
     h->begun = false;
-    bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom);
+    // A single pair in the fused kernel runs on ONE compute unit; beyond a modest size the
+    // multi-kernel path (tiled correspondence over the whole chip) has the lower latency.
+    // Development override: ICPX_FUSED_SINGLE_MAX = largest n*m that stays fused
+    double single_max = kFusedSingleMaxWork;
+    if (const char* e = std::getenv("ICPX_FUSED_SINGLE_MAX")) single_max = std::atof(e);
+    bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom) &&
+                 static_cast<double>(n) * static_cast<double>(m) <= single_max;
     // the tiled brute force of the large path is only chosen explicitly
     h->large = !fused;
     if (h->large && (n == 0 || m == 0)) {

@@ -204,9 +204,14 @@ def test_stepwise_begin_iterate_matches_oracle_every_iteration(icp, ob, scans, d
                 assert np.array_equal(u, v), it
 
 
-def test_fused_sizes_and_overlap_variants(icp, ob):
-    """Every fused-kernel geometry (queries per lane 1/2/4/8) in 2D and 3D, ragged sizes."""
+@pytest.mark.parametrize("single_max", ["1e18", None])
+def test_fused_sizes_and_overlap_variants(icp, ob, monkeypatch, single_max):
+    """Every fused-kernel geometry (queries per lane 1/2/4/8) in 2D and 3D, ragged sizes — with the
+    single-pair size threshold lifted (every size in the fused kernel) and at its default (sizes above
+    ~1024 x 1024 take the multi-kernel path)."""
     from icp_amd import synth
+    if single_max:
+        monkeypatch.setenv("ICPX_FUSED_SINGLE_MAX", single_max)
     crit = dict(max_iterations=12, transform_tol=(1e-5, 1e-5))
     for dim, n, m in [(2, 1, 1), (2, 63, 65), (2, 200, 300), (2, 500, 400), (2, 1000, 1024), (2, 2000, 1500),
                       (2, 4096, 4096), (3, 100, 90), (3, 700, 800), (3, 1500, 1400), (3, 4096, 4096)]:
