@@ -479,6 +479,7 @@ struct Icp : IcpBase {
     KdTree<D> kdtree;         // 3D: built once in setup (vanilla_3d.cpp:75-80)
     std::vector<int64_t> nb_idx;
     std::vector<double> nb_dist;
+    std::vector<double> nfd;  // FeatureAware: normalized_feature_dists, n x m row-major (feature_aware.h:60)
 
     Icp(int method_, const orc_params& p) : method(method_), prm(p) {}
     int dim() const override { return D; }
@@ -522,8 +523,92 @@ struct Icp : IcpBase {
         }
     }
 
+    // ---- FeatureAware (lib/icp/impl/feature_aware.cpp), ICP2 only ----
+    // feature_aware.cpp:151-177.  Feature r of point i: |q_j| - |q_i| for the up to `sn` points before
+    // (packed from row 0) and after (from row sn) it in scan order, q = p - centroid; 0 elsewhere.
+    // The centroid is get_centroid (geo.h:33-37): summation order per prm.sum_mode.
+    std::vector<double> compute_features(const std::vector<double>& pts, int64_t cnt) const {
+        const int64_t sn = prm.symmetric_neighbors;
+        std::vector<double> f(static_cast<size_t>(2 * sn * cnt), 0.0);
+        if (cnt == 0) return f;
+        double c[2];
+        std::vector<double> tmp(static_cast<size_t>(cnt));
+        for (int d = 0; d < 2; d++) {
+            for (int64_t i = 0; i < cnt; i++) tmp[i] = pts[i * 2 + d];
+            c[d] = sum_mode(tmp, prm.sum_mode) / static_cast<double>(cnt);
+        }
+        std::vector<double> rad(static_cast<size_t>(cnt));
+        for (int64_t i = 0; i < cnt; i++) {
+            double dx = pts[i * 2] - c[0], dy = pts[i * 2 + 1] - c[1];
+            rad[i] = std::sqrt(dx * dx + dy * dy);  // (point - centroid).norm()
+        }
+        for (int64_t i = 0; i < cnt; i++) {
+            int64_t lower = std::max<int64_t>(0, i - sn);
+            for (int64_t j = lower; j < i; j++) f[(j - lower) + 2 * sn * i] = rad[j] - rad[i];
+            int64_t upper = std::min<int64_t>(cnt - 1, i + sn);
+            for (int64_t j = i + 1; j <= upper; j++) f[(j - i - 1 + sn) + 2 * sn * i] = rad[j] - rad[i];
+        }
+        return f;
+    }
+
+    // feature_aware.cpp:45-63
+    void setup_feature_aware() {
+        apply_transform_to(a, cur, transform);
+        const int64_t w = 2 * static_cast<int64_t>(prm.symmetric_neighbors);
+        std::vector<double> fa = compute_features(cur, n), fb = compute_features(b, m);
+        nfd.assign(static_cast<size_t>(n * m), 0.0);
+        double mx = -std::numeric_limits<double>::infinity();
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t j = 0; j < m; j++) {
+                // (first.col(i) - second.col(j)).norm(), feature_aware.h:39-41; terms added in row
+                // order (Eigen's packet order for a 2*sn vector is build dependent: parity unpinned)
+                double acc = 0.0;
+                for (int64_t r = 0; r < w; r++) {
+                    double df = fa[r + w * i] - fb[r + w * j];
+                    acc = acc + df * df;
+                }
+                double v = std::sqrt(acc);
+                nfd[i * m + j] = v;
+                if (v > mx) mx = v;
+            }
+        if (mx > 1e-6)  // MIN_NORM_THRESHOLD, feature_aware.cpp:25,56-58
+            for (double& v : nfd) v = v / mx;
+        compute_matches_feature_aware();
+    }
+
+    // feature_aware.cpp:129-149
+    void compute_matches_feature_aware() {
+        if (n == 0) return;
+        const double fw = prm.feature_weight, nw = 1.0 - prm.feature_weight;  // feature_aware.cpp:31
+        std::vector<double> nd(static_cast<size_t>(n * m));
+        double mx = -std::numeric_limits<double>::infinity();
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t j = 0; j < m; j++) {
+                double dx = cur[i * 2] - b[j * 2], dy = cur[i * 2 + 1] - b[j * 2 + 1];
+                double v = std::sqrt(dx * dx + dy * dy);
+                nd[i * m + j] = v;
+                if (v > mx) mx = v;
+            }
+        const bool norm = mx > 1e-6;
+        for (int64_t i = 0; i < n; i++) {
+            matches[i].point = i;
+            matches[i].cost = std::numeric_limits<double>::infinity();
+            // (a match that never finds a cost < inf keeps the pair stored at this position; only
+            // reachable with non-finite input)
+            for (int64_t j = 0; j < m; j++) {
+                double dist = norm ? nd[i * m + j] / mx : nd[i * m + j];
+                double cost = nw * dist + fw * nfd[i * m + j];
+                if (cost < matches[i].cost) {
+                    matches[i].cost = cost;
+                    matches[i].pair = j;
+                }
+            }
+        }
+    }
     void setup() {
-        if (D == 2) {
+        if (D == 2 && method == ORC_FEATURE_AWARE) {
+            setup_feature_aware();
+        } else if (D == 2) {
             // vanilla.cpp:21-26, trimmed.cpp:31-36
             apply_transform_to(a, cur, transform);
             compute_matches_2d();
@@ -623,11 +708,12 @@ struct Icp : IcpBase {
         transform = xf_mul<D>(step, transform);
     }
 
-    // trimmed.cpp:38-93
+    // trimmed.cpp:38-93; feature_aware.cpp:65-127 is the same step around its own compute_matches
     void iterate_trimmed2() {
         if (n == 0 || m == 0) return;  // Q10: the reference is UB here; defined as a no-op
         apply_transform_to(a, cur, transform);
-        compute_matches_2d();
+        if (method == ORC_FEATURE_AWARE) compute_matches_feature_aware();  // feature_aware.cpp:66-86
+        else compute_matches_2d();
         if (prm.sum_mode == ORC_SUM_SEQUENTIAL) {
             // trimmed.cpp:55-56: unstable std::sort on cost only — same libstdc++ here
             std::sort(matches.begin(), matches.end(),
@@ -909,10 +995,12 @@ double orc_sum(const double* v, int64_t n, int mode) {
 }
 
 orc_icp* orc_create(int dim, int method, const orc_params* p) {
-    if ((dim != 2 && dim != 3) || (method != ORC_VANILLA && method != ORC_TRIMMED)) return nullptr;
+    if ((dim != 2 && dim != 3) || method < ORC_VANILLA || method > ORC_FEATURE_AWARE) return nullptr;
+    if (method == ORC_FEATURE_AWARE && dim != 2) return nullptr;  // registered for ICP2 only
     orc_params prm;
     if (p) prm = *p;
-    else prm = orc_params{0.9, 1.0, ORC_NN_KDTREE, ORC_SUM_SEQUENTIAL};
+    else prm = orc_params{0.9, 1.0, ORC_NN_KDTREE, ORC_SUM_SEQUENTIAL, 0.7, 10, 0};
+    if (prm.symmetric_neighbors < 0) return nullptr;
     auto* h = new orc_icp;
     if (dim == 2) h->impl = std::make_unique<Icp<2>>(method, prm);
     else h->impl = std::make_unique<Icp<3>>(method, prm);

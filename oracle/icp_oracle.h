@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-enum { ORC_VANILLA = 0, ORC_TRIMMED = 1 };
+enum { ORC_VANILLA = 0, ORC_TRIMMED = 1, ORC_FEATURE_AWARE = 2 /* ICP2 only */ };
 
 /* how correspondences are found for the kd-tree methods (vanilla 2D, both 3D) */
 enum {
@@ -53,6 +53,9 @@ typedef struct {
     double max_distance; /* Trimmed3d:    trimmed_3d.cpp:27, default 1 */
     int32_t nn_mode;     /* ORC_NN_*  */
     int32_t sum_mode;    /* ORC_SUM_* */
+    double feature_weight;       /* FeatureAware: feature_aware.cpp:23, default 0.7 */
+    int32_t symmetric_neighbors; /* FeatureAware: feature_aware.cpp:24, default 10  */
+    int32_t _pad;
 } orc_params;
 
 /* driver.h:226-233 — one optional per criterion */

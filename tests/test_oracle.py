@@ -139,6 +139,50 @@ def test_reference_2d_cases_on_oracle(ob, method, overlap, modes):
 
 
 @pytest.mark.parametrize("modes", ["ref", "dev"])
+def test_reference_2d_cases_feature_aware_on_oracle(ob, modes):
+    """tests/test.cpp:228-232: the same six cases through feature_aware with overlap_rate 1.0,
+    feature_weight 0.7, symmetric_neighbors 1."""
+    sm = ob.SUM_SEQUENTIAL if modes == "ref" else ob.SUM_TREE64
+    for case in reference_cases_2d():
+        o = ob.OracleICP(2, "feature_aware", overlap_rate=1.0, feature_weight=0.7, symmetric_neighbors=1,
+                         nn_mode=ob.NN_BRUTE, sum_mode=sm)
+        r = o.converge(case[1], case[2], None, ob.make_criteria(**TEST_CRIT))
+        check_case_2d(r.transform, r.iteration_count, case)
+
+
+def test_feature_aware_features_against_numpy(ob, scans):
+    """compute_features / compute_matches (feature_aware.cpp:129-177) restated independently in numpy:
+    the first correspondence step of feature_aware on scan 3 (indices equal, costs to 1e-12)."""
+    a, b = scans[3]
+    sn, fw = 10, 0.7
+
+    def feats(p):
+        c = p.mean(axis=0)
+        rad = np.linalg.norm(p - c, axis=1)
+        f = np.zeros((len(p), 2 * sn))
+        for i in range(len(p)):
+            lo = max(0, i - sn)
+            f[i, : i - lo] = rad[lo:i] - rad[i]
+            hi = min(len(p) - 1, i + sn)
+            f[i, sn: sn + hi - i] = rad[i + 1: hi + 1] - rad[i]
+        return f
+
+    fa, fb = feats(a), feats(b)
+    nfd = np.sqrt(((fa[:, None, :] - fb[None, :, :]) ** 2).sum(axis=2))
+    nfd /= nfd.max()
+    nd = np.sqrt(((a[:, None, :] - b[None, :, :]) ** 2).sum(axis=2))
+    nd /= nd.max()
+    cost = (1 - fw) * nd + fw * nfd
+    o = ob.OracleICP(2, "feature_aware")
+    o.begin(a, b)
+    point, pair, c = o.get_matches()
+    assert np.array_equal(point, np.arange(len(a)))
+    assert np.array_equal(pair, cost.argmin(axis=1))
+    assert np.allclose(c, cost.min(axis=1), rtol=0, atol=1e-12)
+    assert abs(o.calculate_cost() - np.sqrt(cost.min(axis=1).sum() / len(a))) < 1e-12
+
+
+@pytest.mark.parametrize("modes", ["ref", "dev"])
 def test_reference_3d_cases_on_oracle(ob, modes):
     nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if modes == "ref" else (ob.NN_BRUTE, ob.SUM_TREE64)
     for case in reference_cases_3d():
