@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libicpx.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(7)
-VANILLA, TRIMMED = 0, 1
+VANILLA, TRIMMED, FEATURE_AWARE = 0, 1, 2
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 HAS_MIN_ITER, HAS_MAX_ITER, HAS_STOP_COST, HAS_REL_TOL = 1, 2, 4, 8
 HAS_ABS_TOL, HAS_TRANSFORM_TOL, HAS_TIME_LIMIT = 16, 32, 64
@@ -19,7 +19,8 @@ HAS_ABS_TOL, HAS_TRANSFORM_TOL, HAS_TIME_LIMIT = 16, 32, 64
 
 class Params(C.Structure):
     _fields_ = [("overlap_rate", C.c_double), ("max_distance", C.c_double),
-                ("nn_mode", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p)]
+                ("nn_mode", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
+                ("feature_weight", C.c_double), ("symmetric_neighbors", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Criteria(C.Structure):

@@ -88,6 +88,9 @@ class ICP:
         # Trimmed(const Config&): trimmed.cpp:28; Trimmed3d(const Config&): trimmed_3d.cpp:27
         p.overlap_rate = config.get("overlap_rate", 0.9)
         p.max_distance = config.get("max_distance", 1.0)
+        # FeatureAware(const Config&): feature_aware.cpp:38-41
+        p.feature_weight = config.get("feature_weight", 0.7)
+        p.symmetric_neighbors = config.get("symmetric_neighbors", 10)
         # optional, non-reference key: "nn" = "auto" | "brute" | "grid"
         names = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID}
         nn_name = config.get("nn", "")
@@ -165,7 +168,7 @@ class ICP:
 
 class ICP2(ICP):
     dim = 2
-    _methods = {"vanilla": L.VANILLA, "trimmed": L.TRIMMED}
+    _methods = {"vanilla": L.VANILLA, "trimmed": L.TRIMMED, "feature_aware": L.FEATURE_AWARE}
 
 
 class ICP3(ICP):
@@ -278,7 +281,7 @@ def converge_batch(dim, method, sources, source_offsets, targets, target_offsets
     p.max_distance = config.get("max_distance", 1.0)
     p.device = device
     p.stream = stream
-    method = {"vanilla": L.VANILLA, "trimmed": L.TRIMMED}.get(method, method)
+    method = {"vanilla": L.VANILLA, "trimmed": L.TRIMMED, "feature_aware": L.FEATURE_AWARE}.get(method, method)
     so = np.ascontiguousarray(source_offsets, dtype=np.int64)
     to = np.ascontiguousarray(target_offsets, dtype=np.int64)
     n_pairs = len(so) - 1

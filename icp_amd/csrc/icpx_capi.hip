@@ -316,7 +316,8 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     double single_max = kFusedSingleMaxWork;
     if (const char* e = std::getenv("ICPX_FUSED_SINGLE_MAX")) single_max = std::atof(e);
     bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom) &&
-                 static_cast<double>(n) * static_cast<double>(m) <= single_max;
+                 static_cast<double>(n) * static_cast<double>(m) <= single_max &&
+                 h->method != ICPX_FEATURE_AWARE;  // feature_aware runs on the multi-kernel path only
     // the tiled brute force of the large path is only chosen explicitly
     h->large = !fused;
     if (h->large && (n == 0 || m == 0)) {
@@ -339,6 +340,9 @@ void icpx_default_params(icpx_params* p) {
     p->overlap_rate = 0.9;  // trimmed.cpp:28
     p->max_distance = 1.0;  // trimmed_3d.cpp:27
     p->nn_mode = ICPX_NN_AUTO;
+    p->feature_weight = 0.7;       // feature_aware.cpp:23
+    p->symmetric_neighbors = 10;   // feature_aware.cpp:24
+    p->reserved = 0;
     p->device = -1;
     p->stream = nullptr;
 }
@@ -358,8 +362,10 @@ int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out
     if (!out) return fail(ICPX_ERR_INVALID, "null out handle");
     *out = nullptr;
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
-    if (method != ICPX_VANILLA && method != ICPX_TRIMMED)
+    if (method != ICPX_VANILLA && method != ICPX_TRIMMED && method != ICPX_FEATURE_AWARE)
         return fail(ICPX_ERR_INVALID, "unknown method %d", method);
+    if (method == ICPX_FEATURE_AWARE && dim != 2)
+        return fail(ICPX_ERR_INVALID, "feature_aware is an ICP2 method (lib/icp/icp.cpp:17-21)");
     icpx_params prm;
     icpx_default_params(&prm);
     if (params) prm = *params;
@@ -544,6 +550,8 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
                         icpx_state* out_states) {
     auto t0 = std::chrono::steady_clock::now();
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (method == ICPX_FEATURE_AWARE)
+        return fail(ICPX_ERR_UNSUPPORTED, "icpx_converge_batch: feature_aware runs through handles (icpx_converge) only");
     if (method != ICPX_VANILLA && method != ICPX_TRIMMED) return fail(ICPX_ERR_INVALID, "unknown method %d", method);
     if (n_pairs < 0) return fail(ICPX_ERR_INVALID, "negative n_pairs");
     if (n_pairs == 0) return ICPX_OK;

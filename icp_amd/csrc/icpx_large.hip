@@ -51,6 +51,9 @@ struct LargeDev {
     double cost_sum;
     int nn_valid;  // nb_idx holds the previous correspondence step's neighbours (seeds of the tiled search)
     int _pad;
+    // FeatureAware: maxima as f64_key bit patterns (atomicMax), centroids of the two feature passes
+    unsigned long long fmax_key, dmax_key;
+    double fcent[2];
 };
 
 struct LargeIcp {
@@ -71,6 +74,10 @@ struct LargeIcp {
     bool tile = false;
     int splits = 0, split_len = 0;
     DevBuf part_d2, part_idx;
+    // FeatureAware (feature_aware.cpp): radii, features (row r of point i at [r * count + i]) and the
+    // normalised feature-distance matrix, stored target-major ([j * n + i]) for coalesced reads
+    bool feature = false;
+    DevBuf f_rad, f_feat_a, f_feat_b, f_nfd;
     int* h_done = nullptr;  // pinned
 };
 
@@ -99,6 +106,9 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess) {
     dev->ksel = 0.0;
     dev->cost_sum = 0.0;
     dev->nn_valid = 0;
+    dev->fmax_key = 0;
+    dev->dmax_key = 0;
+    dev->fcent[0] = dev->fcent[1] = 0.0;
 }
 
 // NN stage.  MODE 0: the 3D per-iteration stage.  MODE 1: Vanilla::setup's compute_matches on the
@@ -164,6 +174,7 @@ constexpr int kTileQueries = kTileThreads * kTileQpt;
 constexpr int kTileScratch = 96;  // doubles of reduction scratch
 constexpr int kTileMaxSplit = 3072;  // targets per split at most (3D: 110 KB of LDS)
 constexpr int kTileMinSplit = 512;
+constexpr int64_t kFeatureMaxWork = int64_t(1) << 28;  // FeatureAware: n*m doubles of feature distances (2 GiB)
 constexpr int64_t kTileMaxWork = int64_t(1) << 30;  // n*m up to which ICPX_NN_AUTO prefers the tiled search
 
 inline size_t tile_lds_bytes(int dim, int scap) {
@@ -373,6 +384,180 @@ ICPX_DEV double fin_tree(const double* __restrict__ part, int nblk, double* lds)
     }
     __syncthreads();
     return r;
+}
+
+// ---- FeatureAware (lib/icp/impl/feature_aware.cpp), ICP2 --------------------------------------
+ICPX_DEV double key_to_f64(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    return __longlong_as_double(static_cast<long long>(b));
+}
+
+// a_current = transform * a (feature_aware.cpp:46,64); also clears the distance maximum of the
+// matching step that follows
+__global__ void fa_apply_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src,
+                                double* __restrict__ cur, int64_t n) {
+    if (respect_done && dev->st.done) return;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i == 0) dev->dmax_key = 0;
+    if (i >= n) return;
+    Xf<2> X;
+#pragma unroll
+    for (int e = 0; e < 9; e++) X.m[e] = dev->st.transform[e];
+    XfRows<2> xr = xf_rows<2>(X);
+    double p[2] = {src[i * 2], src[i * 2 + 1]}, q[2];
+    xf_apply<2>(xr, p, q);
+    cur[i * 2] = q[0];
+    cur[i * 2 + 1] = q[1];
+}
+
+// get_centroid (geo.h:33-37) in the TREE64 order: block partials, then the remaining levels
+__global__ void __launch_bounds__(kBlk)
+fa_centroid_part_kernel(const double* __restrict__ pts, int64_t cnt, double* __restrict__ part, int nblk) {
+    __shared__ double gs[2 * 64];
+    block_tree<2>([&](int64_t i, double (&v)[2]) {
+        v[0] = pts[i * 2];
+        v[1] = pts[i * 2 + 1];
+    }, cnt, part, nblk, gs);
+}
+__global__ void __launch_bounds__(kBlk)
+fa_centroid_fin_kernel(LargeDev* dev, const double* __restrict__ part, int nblk, int64_t cnt) {
+    __shared__ double lds[64];
+    double sx = fin_tree(part, nblk, lds);
+    double sy = fin_tree(part + nblk, nblk, lds);
+    if (threadIdx.x == 0) {
+        dev->fcent[0] = sx / static_cast<double>(cnt);
+        dev->fcent[1] = sy / static_cast<double>(cnt);
+    }
+}
+// |p_i - centroid| (feature_aware.cpp:159)
+__global__ void fa_radius_kernel(const LargeDev* dev, const double* __restrict__ pts, int64_t cnt,
+                                 double* __restrict__ rad) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    double dx = pts[i * 2] - dev->fcent[0], dy = pts[i * 2 + 1] - dev->fcent[1];
+    rad[i] = __builtin_sqrt(dx * dx + dy * dy);
+}
+// feature_aware.cpp:157-174: feature r of point i, stored at feat[r * cnt + i]
+__global__ void fa_features_kernel(const double* __restrict__ rad, int64_t cnt, int sn, double* __restrict__ feat) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const double ri = rad[i];
+    const int64_t lower = i - sn > 0 ? i - sn : 0;
+    const int64_t upper = i + sn < cnt - 1 ? i + sn : cnt - 1;
+    for (int r = 0; r < sn; r++) {
+        int64_t j = lower + r;
+        feat[static_cast<int64_t>(r) * cnt + i] = j < i ? rad[j] - ri : 0.0;
+        int64_t j2 = i + 1 + r;
+        feat[static_cast<int64_t>(sn + r) * cnt + i] = j2 <= upper ? rad[j2] - ri : 0.0;
+    }
+}
+// compute_norm_dists<Dynamic>(a_features, b_features) (feature_aware.h:33-44): |fa_i - fb_j|, terms
+// added in row order; stored at nfd[j * n + i]; running maximum (feature_aware.cpp:55)
+constexpr int kFaJ = 8;  // targets per thread and launch row
+__global__ void __launch_bounds__(256)
+fa_fdist_kernel(LargeDev* dev, const double* __restrict__ fa, const double* __restrict__ fb, int64_t n, int64_t m, int w,
+                double* __restrict__ nfd) {
+    __shared__ unsigned long long smax[4];
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t j0 = static_cast<int64_t>(blockIdx.y) * kFaJ;
+    unsigned long long mk = 0;
+    if (i < n) {
+        for (int jj = 0; jj < kFaJ; jj++) {
+            int64_t j = j0 + jj;
+            if (j >= m) break;
+            double acc = 0.0;
+            for (int r = 0; r < w; r++) {
+                double df = fa[static_cast<int64_t>(r) * n + i] - fb[static_cast<int64_t>(r) * m + j];
+                acc = acc + df * df;
+            }
+            double v = __builtin_sqrt(acc);
+            nfd[j * n + i] = v;
+            if (v == v) {
+                unsigned long long k = f64_key(v);
+                mk = k > mk ? k : mk;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned long long other = __shfl_xor(mk, o);
+        mk = other > mk ? other : mk;
+    }
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < 4; wv++) mk = smax[wv] > mk ? smax[wv] : mk;
+        if (mk) atomicMax(&dev->fmax_key, mk);
+    }
+}
+// normalized_feature_dists /= max when max > MIN_NORM_THRESHOLD (feature_aware.cpp:56-58)
+__global__ void fa_normalize_kernel(const LargeDev* dev, double* __restrict__ nfd, int64_t total) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total || dev->fmax_key == 0) return;
+    const double mx = key_to_f64(dev->fmax_key);
+    if (mx > 1e-6) nfd[i] = nfd[i] / mx;
+}
+// maxCoeff of compute_norm_dists<2>(a_current, b) (feature_aware.cpp:130-131): sqrt is monotone, so
+// the maximum squared distance is tracked
+__global__ void __launch_bounds__(256)
+fa_maxdist_kernel(LargeDev* dev, int respect_done, const double* __restrict__ cur, int64_t n,
+                  const double* __restrict__ dst, int64_t m, int split_len) {
+    __shared__ unsigned long long smax[4];
+    if (respect_done && dev->st.done) return;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
+    const int64_t t1 = t0 + split_len < m ? t0 + split_len : m;
+    double mx = -1.0;
+    if (i < n) {
+        const double qx = cur[i * 2], qy = cur[i * 2 + 1];
+        for (int64_t j = t0; j < t1; j++) {
+            double dx = qx - dst[j * 2], dy = qy - dst[j * 2 + 1];
+            double d2 = dx * dx + dy * dy;
+            mx = d2 > mx ? d2 : mx;
+        }
+    }
+    unsigned long long mk = mx >= 0.0 ? f64_key(mx) : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned long long other = __shfl_xor(mk, o);
+        mk = other > mk ? other : mk;
+    }
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < 4; wv++) mk = smax[wv] > mk ? smax[wv] : mk;
+        if (mk) atomicMax(&dev->dmax_key, mk);
+    }
+}
+// FeatureAware::compute_matches (feature_aware.cpp:129-149) over one target split: cost =
+// neighbor_weight * dist / max + feature_weight * normalized_feature_dist, strict <, ascending j
+__global__ void __launch_bounds__(256)
+fa_match_kernel(const LargeDev* dev, int respect_done, const double* __restrict__ cur, int64_t n,
+                const double* __restrict__ dst, int64_t m, int split_len, const double* __restrict__ nfd,
+                double feature_weight, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
+    if (respect_done && dev->st.done) return;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
+    const int64_t t1 = t0 + split_len < m ? t0 + split_len : m;
+    const double nw = 1.0 - feature_weight;  // feature_aware.cpp:31
+    const double mx = dev->dmax_key ? __builtin_sqrt(key_to_f64(dev->dmax_key)) : 0.0;
+    const bool norm = mx > 1e-6;
+    const double qx = cur[i * 2], qy = cur[i * 2 + 1];
+    double best = __builtin_inf();
+    int32_t bi = 0x7fffffff;
+    for (int64_t j = t0; j < t1; j++) {
+        double dx = qx - dst[j * 2], dy = qy - dst[j * 2 + 1];
+        double dist = __builtin_sqrt(dx * dx + dy * dy);
+        if (norm) dist = dist / mx;
+        double cost = nw * dist + feature_weight * nfd[j * n + i];
+        if (cost < best) {
+            best = cost;
+            bi = static_cast<int32_t>(j);
+        }
+    }
+    part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = best;
+    part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = bi;
 }
 
 template <int D, int METHOD>
@@ -756,7 +941,7 @@ void large_destroy(LargeIcp* lg) {
     (void)hipStreamSynchronize(lg->stream);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
                       &lg->cntp, &lg->dev, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
-                      &lg->part_d2, &lg->part_idx})
+                      &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd})
         b->release();
     grid_destroy(lg->grid);
     if (lg->h_done) (void)hipHostFree(lg->h_done);
@@ -787,11 +972,75 @@ int enqueue_sums(LargeIcp* lg, int respect_done, bool second) {
     return ICPX_OK;
 }
 
+// FeatureAware::compute_matches (feature_aware.cpp:129-149): a_current, the maximum pairwise
+// distance, the weighted-cost argmin per target split, the merge
+int enqueue_feature_match(LargeIcp* lg, int respect) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+    dim3 grid(nb, static_cast<unsigned>(lg->splits));
+    hipLaunchKernelGGL(fa_apply_kernel, dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->src.as<double>(),
+                       lg->cur.as<double>(), lg->n);
+    ICPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fa_maxdist_kernel, grid, dim3(256), 0, lg->stream, dev, respect, lg->cur.as<double>(), lg->n,
+                       lg->dst.as<double>(), lg->m, lg->split_len);
+    ICPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fa_match_kernel, grid, dim3(256), 0, lg->stream, dev, respect, lg->cur.as<double>(), lg->n,
+                       lg->dst.as<double>(), lg->m, lg->split_len, lg->f_nfd.as<double>(), lg->prm.feature_weight,
+                       lg->part_d2.as<double>(), lg->part_idx.as<int32_t>());
+    ICPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL((lg_tile_merge_kernel<2, ICPX_TRIMMED, 2>), dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n,
+                       lg->splits, lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->nb_idx.as<int64_t>(),
+                       lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+// compute_features of one cloud (feature_aware.cpp:151-177) into feat[r * cnt + i]
+int enqueue_features(LargeIcp* lg, const double* pts, int64_t cnt, double* feat) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const int nblk = static_cast<int>((cnt + kBlkPts - 1) / kBlkPts);
+    const unsigned nb = static_cast<unsigned>((cnt + 255) / 256);
+    hipLaunchKernelGGL(fa_centroid_part_kernel, dim3(nblk), dim3(kBlk), 0, lg->stream, pts, cnt, lg->part.as<double>(), nblk);
+    ICPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fa_centroid_fin_kernel, dim3(1), dim3(kBlk), 0, lg->stream, dev, lg->part.as<double>(), nblk, cnt);
+    ICPX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fa_radius_kernel, dim3(nb), dim3(256), 0, lg->stream, dev, pts, cnt, lg->f_rad.as<double>());
+    ICPX_HIP(hipGetLastError());
+    if (lg->prm.symmetric_neighbors > 0) {
+        hipLaunchKernelGGL(fa_features_kernel, dim3(nb), dim3(256), 0, lg->stream, lg->f_rad.as<double>(), cnt,
+                           lg->prm.symmetric_neighbors, feat);
+        ICPX_HIP(hipGetLastError());
+    }
+    return ICPX_OK;
+}
+
+// FeatureAware::setup up to (not including) compute_matches (feature_aware.cpp:45-59)
+int enqueue_feature_setup(LargeIcp* lg) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+    hipLaunchKernelGGL(fa_apply_kernel, dim3(nb), dim3(256), 0, lg->stream, dev, 0, lg->src.as<double>(),
+                       lg->cur.as<double>(), lg->n);
+    ICPX_HIP(hipGetLastError());
+    ICPX_TRY(enqueue_features(lg, lg->cur.as<double>(), lg->n, lg->f_feat_a.as<double>()));
+    ICPX_TRY(enqueue_features(lg, lg->dst.as<double>(), lg->m, lg->f_feat_b.as<double>()));
+    const int w = 2 * lg->prm.symmetric_neighbors;
+    dim3 grid(nb, static_cast<unsigned>((lg->m + kFaJ - 1) / kFaJ));
+    hipLaunchKernelGGL(fa_fdist_kernel, grid, dim3(256), 0, lg->stream, dev, lg->f_feat_a.as<double>(),
+                       lg->f_feat_b.as<double>(), lg->n, lg->m, w, lg->f_nfd.as<double>());
+    ICPX_HIP(hipGetLastError());
+    const int64_t total = lg->n * lg->m;
+    hipLaunchKernelGGL(fa_normalize_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, lg->stream,
+                       dev, lg->f_nfd.as<double>(), total);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
 // the correspondence stage of one step: the tiled brute force (mid-size clouds) or the grid walk
 template <int D, int METHOD, int MODE>
 int enqueue_nn(LargeIcp* lg, int respect) {
     LargeDev* dev = lg->dev.as<LargeDev>();
     const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+    if (lg->feature) return enqueue_feature_match(lg, respect);
     if (!lg->tile) {
         hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
@@ -836,6 +1085,7 @@ int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double hos
     hipLaunchKernelGGL(lg_init_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->guess.as<double>());
     ICPX_HIP(hipGetLastError());
     if (D == 2) {
+        if (lg->feature) ICPX_TRY(enqueue_feature_setup(lg));
         ICPX_TRY((enqueue_nn<D, METHOD, METHOD == ICPX_TRIMMED ? 2 : 1>(lg, 0)));
         ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
     }
@@ -913,8 +1163,9 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     ICPX_HIP(hipMemcpyAsync(lg->cur.p, lg->src.p, sizeof(double) * D * n, hipMemcpyDeviceToDevice, lg->stream));
     ICPX_HIP(hipMemsetAsync(lg->sel.p, 1, n, lg->stream));
     lg->sorted = false;
-    if (D == 2 && lg->method == ICPX_TRIMMED) {
-        // trimmed.cpp:57-58 (overlap_rate > 1 would read out of range there; clamped here)
+    lg->feature = D == 2 && lg->method == ICPX_FEATURE_AWARE;
+    if (D == 2 && lg->method != ICPX_VANILLA) {
+        // trimmed.cpp:57-58, feature_aware.cpp:92-93 (overlap_rate > 1 would read out of range there; clamped here)
         long long k = static_cast<long long>(lg->prm.overlap_rate * static_cast<double>(n));
         lg->new_n = std::min<long long>(std::max<long long>(k, 1), n);
         ICPX_TRY(lg->sort_keys.reserve(sizeof(unsigned long long) * n));
@@ -933,7 +1184,7 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     }
     // correspondence engine: tiled brute force for mid-size clouds, the uniform grid beyond
     // (ICPX_NN_GRID / ICPX_NN_BRUTE force one or the other)
-    lg->tile = lg->prm.nn_mode == ICPX_NN_BRUTE ||
+    lg->tile = lg->feature || lg->prm.nn_mode == ICPX_NN_BRUTE ||
                (lg->prm.nn_mode != ICPX_NN_GRID && static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
     if (lg->tile) {
         const int64_t ntq = (n + kTileQueries - 1) / kTileQueries;
@@ -951,6 +1202,21 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         ICPX_TRY(lg->part_idx.reserve(sizeof(int32_t) * static_cast<size_t>(splits) * n));
     } else {
         ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
+    }
+    if (lg->feature) {
+        // the reference keeps the dense n x m feature-distance matrix too (feature_aware.h:60)
+        if (static_cast<double>(n) * static_cast<double>(m) > static_cast<double>(kFeatureMaxWork))
+            return fail(ICPX_ERR_UNSUPPORTED, "feature_aware keeps an n x m matrix: n*m is limited to %lld",
+                        (long long)kFeatureMaxWork);
+        if (lg->prm.symmetric_neighbors < 0 || lg->prm.symmetric_neighbors > 4096)
+            return fail(ICPX_ERR_INVALID, "symmetric_neighbors out of range");
+        const size_t w = 2 * static_cast<size_t>(lg->prm.symmetric_neighbors);
+        const int64_t big = n > m ? n : m;
+        ICPX_TRY(lg->part.reserve(sizeof(double) * 16 * static_cast<size_t>((big + kBlkPts - 1) / kBlkPts)));
+        ICPX_TRY(lg->f_rad.reserve(sizeof(double) * big));
+        ICPX_TRY(lg->f_feat_a.reserve(sizeof(double) * (w * n + 1)));
+        ICPX_TRY(lg->f_feat_b.reserve(sizeof(double) * (w * m + 1)));
+        ICPX_TRY(lg->f_nfd.reserve(sizeof(double) * static_cast<size_t>(n) * m));
     }
     return LG_DISPATCH(enqueue_setup, lg, 0, zero_criteria(), 0.0);
 }
@@ -1016,7 +1282,7 @@ int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost) {
     // 2D only (3D is answered by the caller).  Vanilla: point order.  Trimmed: point order after
     // begin, the sorted order Trimmed::iterate leaves behind (trimmed.cpp:55-56) afterwards.
     const int64_t n = lg->n;
-    const bool by_order = lg->method == ICPX_TRIMMED && lg->sorted;
+    const bool by_order = lg->method != ICPX_VANILLA && lg->sorted;
     DevBuf tp, tq, tc;
     int rc = tp.reserve(sizeof(int64_t) * n);
     if (rc == ICPX_OK) rc = tq.reserve(sizeof(int64_t) * n);

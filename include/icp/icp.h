@@ -135,19 +135,20 @@ namespace icp {
 }
 
 #include "icp/impl/device_icp.h"
+#include "icp/impl/feature_aware.h"
 #include "icp/impl/trimmed.h"
 #include "icp/impl/trimmed_3d.h"
 #include "icp/impl/vanilla.h"
 #include "icp/impl/vanilla_3d.h"
 
 namespace icp {
-    // lib/icp/icp.cpp:17-21 registers vanilla / trimmed / feature_aware for ICP2; feature_aware is
-    // outside this build's scope and is not registered.
+    // lib/icp/icp.cpp:17-21
     template<>
     inline std::unordered_map<std::string, ICP2::MethodConstructor>& ICP2::methods() {
         static std::unordered_map<std::string, MethodConstructor> m = {
             {"vanilla", [](const Config& c) { return std::make_unique<Vanilla>(c); }},
             {"trimmed", [](const Config& c) { return std::make_unique<Trimmed>(c); }},
+            {"feature_aware", [](const Config& c) { return std::make_unique<FeatureAware>(c); }},
         };
         return m;
     }

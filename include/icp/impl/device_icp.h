@@ -20,6 +20,8 @@ namespace icp {
             icpx_default_params(&p);
             p.overlap_rate = config.get<double>("overlap_rate", p.overlap_rate);  // trimmed.cpp:28
             p.max_distance = config.get<double>("max_distance", p.max_distance);  // trimmed_3d.cpp:27
+            p.feature_weight = config.get<double>("feature_weight", p.feature_weight);                // feature_aware.cpp:40
+            p.symmetric_neighbors = config.get<int>("symmetric_neighbors", p.symmetric_neighbors);    // feature_aware.cpp:41
             // optional, non-reference keys
             p.device = config.get<int>("device", -1);
             const std::string nn = config.get<std::string>("nn", "auto");

@@ -53,7 +53,8 @@ enum icpx_status {
 /* ICP<Dim>::methods registry names (lib/icp/icp.cpp:17-27) */
 enum icpx_method {
     ICPX_VANILLA = 0, /* "vanilla": Vanilla (2D, vanilla.cpp) / Vanilla3d (vanilla_3d.cpp) */
-    ICPX_TRIMMED = 1  /* "trimmed": Trimmed (2D, trimmed.cpp) / Trimmed3d (trimmed_3d.cpp) */
+    ICPX_TRIMMED = 1, /* "trimmed": Trimmed (2D, trimmed.cpp) / Trimmed3d (trimmed_3d.cpp) */
+    ICPX_FEATURE_AWARE = 2 /* "feature_aware": FeatureAware (2D only, feature_aware.cpp)      */
 };
 
 enum icpx_nn_mode {
@@ -69,6 +70,9 @@ typedef struct icpx_params {
     int32_t nn_mode;     /* enum icpx_nn_mode                                                   */
     int32_t device;      /* HIP device ordinal; -1 = the calling thread's current device        */
     void* stream;        /* hipStream_t to run on; NULL = the null stream                       */
+    double feature_weight;       /* Config "feature_weight" — FeatureAware, feature_aware.cpp:23, default 0.7      */
+    int32_t symmetric_neighbors; /* Config "symmetric_neighbors" — FeatureAware, feature_aware.cpp:24, default 10 */
+    int32_t reserved;            /* 0 */
 } icpx_params;
 
 /* ICPDriver's optional termination criteria (include/icp/driver.h:80-151, 226-233). */

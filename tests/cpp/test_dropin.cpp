@@ -273,6 +273,9 @@ void test_interface_semantics() {
     // registry (icp.h:95-114)
     assert_true(icp::ICP2::is_method_registered("vanilla"));
     assert_true(icp::ICP2::is_method_registered("trimmed"));
+    assert_true(icp::ICP2::is_method_registered("feature_aware"));
+    assert_true(icp::ICP2::registered_methods().size() == 3);  // lib/icp/icp.cpp:17-21
+    assert_true(!icp::ICP3::is_method_registered("feature_aware"));
     assert_true(!icp::ICP2::is_method_registered("nope"));
     assert_true(!icp::ICP2::from_method("nope", icp::Config()).has_value());
     assert_true(icp::ICP3::registered_methods().size() == 2);
@@ -325,6 +328,12 @@ int main() {
     icp::Config trimmed_config;
     trimmed_config.set("overlap_rate", 1.0);  // tests/test.cpp:223-226
     test_icp_generic("trimmed", trimmed_config);
+    // tests/test.cpp:228-232
+    icp::Config feature_config;
+    feature_config.set("overlap_rate", 1.0);
+    feature_config.set("feature_weight", 0.7);
+    feature_config.set("symmetric_neighbors", 1);
+    test_icp_generic("feature_aware", feature_config);
     test_icp_3d(icp::Config());
     test_interface_semantics();
     std::printf("%d checks, %d failed\n", g_checked, g_failed);

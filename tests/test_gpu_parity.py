@@ -408,6 +408,59 @@ def test_filtered_search_adversarial_inputs(icp, ob):
                 assert np.array_equal(u, v), (kind, it)
 
 
+def test_feature_aware_matches_oracle(icp, ob, scans):
+    """FeatureAware (ICP2) on the multi-kernel path — features, normalised feature
+    distances, weighted-cost matches, trimming, Kabsch — bit-exact against the oracle in device
+    summation order, every iteration and through the driver; 1e-6 against the reference order."""
+    for k, (a, b) in scans.items():
+        x = icp.ICP2.from_method("feature_aware")
+        o = dev_oracle(ob, 2, "feature_aware")
+        g = np.eye(3)
+        g[:2, 2] = (0.02, -0.01)
+        x.begin(a, b, g)
+        o.begin(a, b, g)
+        assert x.calculate_cost() == o.calculate_cost(), k
+        for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+            assert np.array_equal(u, v), k
+        for it in range(3):
+            x.iterate()
+            o.iterate()
+            assert np.array_equal(x.current_transform(), o.current_transform()), (k, it)
+            assert x.calculate_cost() == o.calculate_cost(), (k, it)
+            for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+                assert np.array_equal(u, v), (k, it)
+        r = driver(icp, icp.ICP2, "feature_aware", BENCH_CRIT).converge(a, b)
+        ro = o.converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
+        assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform), k
+        assert r.cost == ro.cost
+        rs = ob.OracleICP(2, "feature_aware").converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
+        assert rs.iteration_count == r.iteration_count
+        assert np.abs(rs.transform - r.transform).max() < TOL
+    # other parameters, ragged sizes, the reference's own test configuration (tests/test.cpp:228-232)
+    rng = np.random.default_rng(9)
+    for n, m, sn, fw, ov in ((300, 417, 1, 0.7, 1.0), (5000, 4100, 3, 0.2, 0.5), (64, 5, 0, 0.7, 0.9), (7, 900, 25, 1.0, 0.9)):
+        t = np.cumsum(rng.normal(0, 0.05, (m, 2)), axis=0) + rng.uniform(-3, 3, 2)
+        s = np.cumsum(rng.normal(0, 0.05, (n, 2)), axis=0) + rng.uniform(-3, 3, 2)
+        cfg = icp.Config()
+        cfg.set("overlap_rate", ov)
+        cfg.set("feature_weight", fw)
+        cfg.set("symmetric_neighbors", sn)
+        crit = dict(max_iterations=5)
+        r = driver(icp, icp.ICP2, "feature_aware", crit, cfg).converge(s, t)
+        ro = dev_oracle(ob, 2, "feature_aware", overlap_rate=ov, feature_weight=fw, symmetric_neighbors=sn).converge(
+            s, t, None, ob.make_criteria(**crit))
+        assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform), (n, m, sn)
+        assert r.cost == ro.cost, (n, m, sn)
+    cfg = icp.Config()
+    cfg.set("overlap_rate", 1.0)
+    cfg.set("feature_weight", 0.7)
+    cfg.set("symmetric_neighbors", 1)
+    for case in reference_cases_2d():
+        r = driver(icp, icp.ICP2, "feature_aware", TEST_CRIT, cfg).converge(case[1], case[2])
+        check_case_2d(r.transform, r.iteration_count, case)
+    assert icp.ICP3.from_method("feature_aware") is None  # registered for ICP2 only (lib/icp/icp.cpp:17-27)
+
+
 def test_driver_criteria_on_device(icp, ob, scans):
     a, b = scans[1]
     for crit in [dict(max_iterations=5), dict(max_iterations=0), dict(min_iterations=7, max_iterations=50, stop_cost=1e9),

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     from icp_amd import _lib
     assert C.sizeof(_lib.State) == 144
     assert C.sizeof(_lib.Criteria) == 72
-    assert C.sizeof(_lib.Params) == 32
+    assert C.sizeof(_lib.Params) == 48
 
 
 def _has_gpu():
@@ -53,7 +53,7 @@ def test_fails_loudly_without_device():
 
 def test_registry_and_config_semantics():
     import icp_amd
-    assert sorted(icp_amd.ICP2.registered_methods()) == ["trimmed", "vanilla"]
+    assert sorted(icp_amd.ICP2.registered_methods()) == ["feature_aware", "trimmed", "vanilla"]
     assert sorted(icp_amd.ICP3.registered_methods()) == ["trimmed", "vanilla"]
     assert icp_amd.ICP2.is_method_registered("trimmed")
     assert not icp_amd.ICP2.is_method_registered("nope")
