@@ -175,6 +175,7 @@ def main():
             line["extras"] = extras(torch, icp_amd, synth, dev, local_rank, stream)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(s2, t2, off2, s3, t3, off3, args.cpu_sample)
+            line["cpu_baseline_all_cores"] = cpu_baseline_threads(s2, t2, off2, s3, t3, off3, args.cpu_sample)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -270,6 +271,45 @@ def cpu_baseline(s2, t2, off2, s3, t3, off3, sample):
         "sample": f"first {k2} 2D pairs + first {k3} 3D pairs of rank 0's shard, {dt:.1f} s of CPU time; "
                   "oracle in reference order (brute-force NN + std::sort for trimmed ICP2, kd-tree NN for "
                   "vanilla ICP3, sequential sums), g++ -O3 -DNDEBUG",
+    }
+
+
+def cpu_baseline_threads(s2, t2, off2, s3, t3, off3, sample):
+    """the same oracle run over the same pairs, pairs spread over the host cores this
+    process may use (one oracle instance per worker thread; ctypes releases the GIL).  The reference
+    itself is single-threaded: this is the embarrassingly parallel upper bound a user could build."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as ob
+    crit = ob.make_criteria(max_iterations=MAX_ITER, transform_tol=TOL)
+    k2, k3 = min(sample, PAIRS_2D), min(sample, PAIRS_3D)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)), 64))
+
+    def work(w):
+        q = 0
+        o2, o3 = ob.OracleICP(2, "trimmed"), ob.OracleICP(3, "vanilla")
+        for p in range(w, k3, cores):  # the expensive pairs first
+            r = o3.converge(s3[off3[p]:off3[p + 1]], t3[off3[p]:off3[p + 1]], None, crit)
+            q += r.iteration_count * N_3D
+        for p in range(w, k2, cores):
+            r = o2.converge(s2[off2[p]:off2[p + 1]], t2[off2[p]:off2[p + 1]], None, crit)
+            q += (r.iteration_count + 1) * N_2D
+        return q
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        queries = sum(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    return {
+        "value": queries / dt,
+        "unit": "queries/s",
+        "pairs_per_s": (k2 + k3) / dt,
+        "cores": cores,
+        "kind": "port",
+        "sample": f"the same {k2} + {k3} pairs spread over {cores} worker threads, {dt:.1f} s wall",
     }
 
 
