@@ -91,6 +91,10 @@ class ICP:
         # FeatureAware(const Config&): feature_aware.cpp:38-41
         p.feature_weight = config.get("feature_weight", 0.7)
         p.symmetric_neighbors = config.get("symmetric_neighbors", 10)
+        # optional, non-reference keys (ints 0/1): opt-in corrections of reference quirks Q1 / Q4 / Q5
+        p.flags = ((L.FLAG_MATCH_TRANSFORMED if config.get("match_transformed", 0) else 0) |
+                   (L.FLAG_FILL_MATCHES if config.get("fill_matches", 0) else 0) |
+                   (L.FLAG_APPLY_GUESS if config.get("apply_guess", 0) else 0))
         # optional, non-reference key: "nn" = "auto" | "brute" | "grid"
         names = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID}
         nn_name = config.get("nn", "")

@@ -317,7 +317,8 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     if (const char* e = std::getenv("ICPX_FUSED_SINGLE_MAX")) single_max = std::atof(e);
     bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom) &&
                  static_cast<double>(n) * static_cast<double>(m) <= single_max &&
-                 h->method != ICPX_FEATURE_AWARE;  // feature_aware runs on the multi-kernel path only
+                 h->method != ICPX_FEATURE_AWARE &&  // feature_aware and the opt-in corrected modes run on
+                 h->prm.flags == 0;                  // the multi-kernel path only
     // the tiled brute force of the large path is only chosen explicitly
     h->large = !fused;
     if (h->large && (n == 0 || m == 0)) {
@@ -342,7 +343,7 @@ void icpx_default_params(icpx_params* p) {
     p->nn_mode = ICPX_NN_AUTO;
     p->feature_weight = 0.7;       // feature_aware.cpp:23
     p->symmetric_neighbors = 10;   // feature_aware.cpp:24
-    p->reserved = 0;
+    p->flags = 0;
     p->device = -1;
     p->stream = nullptr;
 }
@@ -371,6 +372,7 @@ int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out
     if (params) prm = *params;
     if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_GRID)
         return fail(ICPX_ERR_INVALID, "unknown nn_mode %d", prm.nn_mode);
+    if (prm.flags < 0 || prm.flags > 7) return fail(ICPX_ERR_INVALID, "unknown flags %d", prm.flags);
     int dev = 0;
     ICPX_TRY(resolve_device(prm.device, &dev));
     DeviceInfo* di = nullptr;
@@ -511,6 +513,11 @@ int icpx_matches(icpx_handle h, int64_t* point, int64_t* pair, double* cost) {
     if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_matches before icpx_begin");
     const int64_t n = h->n;
     if (n == 0) return ICPX_OK;
+    if (h->dim == 3 && h->large && (h->prm.flags & ICPX_FLAG_FILL_MATCHES)) {
+        DeviceGuard g3;
+        ICPX_TRY(g3.enter(h->device));
+        return large_matches(h->lg, point, pair, cost);  // opt-in: (point, neighbour, distance)
+    }
     if (h->dim == 3) {
         // Vanilla3d / Trimmed3d never touch `matches` (icp.h:129 value-initialises them)
         if (point) std::memset(point, 0, sizeof(int64_t) * n);
@@ -550,8 +557,9 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
                         icpx_state* out_states) {
     auto t0 = std::chrono::steady_clock::now();
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
-    if (method == ICPX_FEATURE_AWARE)
-        return fail(ICPX_ERR_UNSUPPORTED, "icpx_converge_batch: feature_aware runs through handles (icpx_converge) only");
+    if (method == ICPX_FEATURE_AWARE || (params && params->flags != 0))
+        return fail(ICPX_ERR_UNSUPPORTED,
+                    "icpx_converge_batch: feature_aware and the opt-in corrected modes run through handles (icpx_converge) only");
     if (method != ICPX_VANILLA && method != ICPX_TRIMMED) return fail(ICPX_ERR_INVALID, "unknown method %d", method);
     if (n_pairs < 0) return fail(ICPX_ERR_INVALID, "negative n_pairs");
     if (n_pairs == 0) return ICPX_OK;

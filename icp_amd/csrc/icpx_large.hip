@@ -54,6 +54,8 @@ struct LargeDev {
     // FeatureAware: maxima as f64_key bit patterns (atomicMax), centroids of the two feature passes
     unsigned long long fmax_key, dmax_key;
     double fcent[2];
+    int with_cost;    // the matches carry a cost that ICP::calculate_cost sums (2D; 3D with ICPX_FLAG_FILL_MATCHES)
+    int update_cost;  // that cost changes in every iterate (not for reference 2D vanilla, Q1)
 };
 
 struct LargeIcp {
@@ -88,7 +90,7 @@ struct LargeIcp {
 namespace {
 
 template <int D>
-__global__ void lg_init_kernel(LargeDev* dev, const double* guess) {
+__global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost, int update_cost) {
     constexpr int XN = (D + 1) * (D + 1);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int e = 0; e < 16; e++) {
@@ -106,6 +108,8 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess) {
     dev->ksel = 0.0;
     dev->cost_sum = 0.0;
     dev->nn_valid = 0;
+    dev->with_cost = with_cost;
+    dev->update_cost = update_cost;
     dev->fmax_key = 0;
     dev->dmax_key = 0;
     dev->fcent[0] = dev->fcent[1] = 0.0;
@@ -113,7 +117,8 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess) {
 
 // NN stage.  MODE 0: the 3D per-iteration stage.  MODE 1: Vanilla::setup's compute_matches on the
 // untransformed source (vanilla.cpp:68-88).  MODE 2: Trimmed::compute_matches on transform*a with
-// the squared distance as cost (trimmed.cpp:95-109).
+// the squared distance as cost (trimmed.cpp:95-109).  MODE 3: Vanilla's compute_matches on
+// transform*a (opt-in ICPX_FLAG_MATCH_TRANSFORMED, not reference behaviour).
 template <int D, int METHOD, int MODE>
 __global__ void __launch_bounds__(256)
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
@@ -127,7 +132,7 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     if (MODE == 1) {
 #pragma unroll
         for (int d = 0; d < D; d++) q[d] = src[i * D + d];
-    } else if (MODE == 2) {
+    } else if (MODE == 2 || MODE == 3) {
         Xf<D> X;
 #pragma unroll
         for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
@@ -179,6 +184,21 @@ constexpr int64_t kTileMaxWork = int64_t(1) << 30;  // n*m up to which ICPX_NN_A
 
 inline size_t tile_lds_bytes(int dim, int scap) {
     return sizeof(double) * (static_cast<size_t>(dim) * scap + kTileScratch) + sizeof(float) * static_cast<size_t>(dim) * scap;
+}
+
+__global__ void lg_apply_guess_kernel(const double* __restrict__ guess, const double* __restrict__ src,
+                                      double* __restrict__ cur, int64_t n) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xf<3> G;
+#pragma unroll
+    for (int e = 0; e < 16; e++) G.m[e] = guess[e];
+    XfRows<3> gr = xf_rows<3>(G);
+    double p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]}, q[3];
+    xf_apply<3>(gr, p, q);
+    cur[i * 3] = q[0];
+    cur[i * 3 + 1] = q[1];
+    cur[i * 3 + 2] = q[2];
 }
 
 template <int D>
@@ -233,7 +253,7 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     const int64_t qbase = static_cast<int64_t>(blockIdx.x) * kTileQueries;
     const bool seeded = dev->nn_valid != 0;
     XfRows<D> xr;
-    if (MODE == 2) {
+    if (MODE == 2 || MODE == 3) {
         Xf<D> X;
 #pragma unroll
         for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
@@ -246,7 +266,7 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
         double pnt[D];
 #pragma unroll
         for (int d = 0; d < D; d++) pnt[d] = valid ? (MODE == 0 ? cur[i * D + d] : src[i * D + d]) : 0.0;
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 3) {
             xf_apply<D>(xr, pnt, q[k]);  // a_current = transform * a, trimmed.cpp:40
         } else {
 #pragma unroll
@@ -573,6 +593,7 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
 #pragma unroll
     for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
     XfRows<D> xr = xf_rows<D>(X);
+    const bool with_cost = dev->with_cost != 0;
     int cnt = 0;
     const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
     for (int k = 0; k < kSlots; k++) {
@@ -597,7 +618,7 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
                 v[d] = s ? c[d] : 0.0;
                 v[D + d] = s ? dst[j * D + d] : 0.0;
             }
-            v[2 * D] = D == 2 ? nb_cost[i] : 0.0;
+            v[2 * D] = with_cost ? nb_cost[i] : 0.0;
         },
         n, part, nblk, gs);
     cnt = wave_sum_int(cnt);
@@ -676,7 +697,7 @@ template <int D>
 __global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx_criteria crit,
                                        double clock_to_s, double host_elapsed_s) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double sum = D == 2 ? dev->cost_sum : 0.0;
+    double sum = dev->with_cost ? dev->cost_sum : 0.0;
     dev->st.cost = __builtin_sqrt(sum / static_cast<double>(n));  // icp.h:149-155
     if (check) {
         double el = host_elapsed_s + static_cast<double>(wall_clock64() - dev->st.start_clock) * clock_to_s;
@@ -719,7 +740,7 @@ lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
         dev->st.iteration_count += 1;
         // cost: 2D vanilla's matches never change (vanilla.cpp:80); ICP3 never fills them (Q4);
         // trimmed ICP2 rates the matches this iteration computed (icp.h:149-155)
-        if (D == 2 && METHOD == ICPX_TRIMMED) dev->st.cost = __builtin_sqrt(dev->cost_sum / n_points);
+        if (dev->update_cost) dev->st.cost = __builtin_sqrt(dev->cost_sum / n_points);
         if (check) {
             double el = host_elapsed_s + static_cast<double>(wall_clock64() - dev->st.start_clock) * clock_to_s;
             if (should_terminate<D>(crit, dev->st, el)) {
@@ -1082,11 +1103,21 @@ int enqueue_nn(LargeIcp* lg, int respect) {
 template <int D, int METHOD>
 int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
     LargeDev* dev = lg->dev.as<LargeDev>();
-    hipLaunchKernelGGL(lg_init_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->guess.as<double>());
+    const bool match_tf = D == 2 && METHOD == ICPX_VANILLA && (lg->prm.flags & ICPX_FLAG_MATCH_TRANSFORMED);
+    const bool fill3 = D == 3 && (lg->prm.flags & ICPX_FLAG_FILL_MATCHES);
+    const int with_cost = (D == 2 || fill3) ? 1 : 0;
+    const int update_cost = ((D == 2 && METHOD != ICPX_VANILLA) || match_tf || fill3) ? 1 : 0;
+    hipLaunchKernelGGL(lg_init_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->guess.as<double>(), with_cost,
+                       update_cost);
     ICPX_HIP(hipGetLastError());
     if (D == 2) {
         if (lg->feature) ICPX_TRY(enqueue_feature_setup(lg));
-        ICPX_TRY((enqueue_nn<D, METHOD, METHOD == ICPX_TRIMMED ? 2 : 1>(lg, 0)));
+        if (match_tf) ICPX_TRY((enqueue_nn<D, METHOD, 3>(lg, 0)));
+        else ICPX_TRY((enqueue_nn<D, METHOD, METHOD == ICPX_TRIMMED ? 2 : 1>(lg, 0)));
+        ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
+    } else if (fill3) {
+        // opt-in: the 3D methods fill `matches` in setup too (step is the identity here)
+        ICPX_TRY((enqueue_nn<D, METHOD, 0>(lg, 0)));
         ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
     }
     hipLaunchKernelGGL(lg_setup_finish_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, check, crit,
@@ -1100,6 +1131,7 @@ int enqueue_iteration(LargeIcp* lg, int check, const icpx_criteria& crit, double
     LargeDev* dev = lg->dev.as<LargeDev>();
     const int respect = check;
     if (D == 3 || METHOD == ICPX_TRIMMED) ICPX_TRY((enqueue_nn<D, METHOD, D == 3 ? 0 : 2>(lg, respect)));
+    else if (lg->prm.flags & ICPX_FLAG_MATCH_TRANSFORMED) ICPX_TRY((enqueue_nn<D, METHOD, 3>(lg, respect)));
     if (D == 2 && METHOD == ICPX_TRIMMED) {
         // std::sort by cost (trimmed.cpp:55-56) made total: a stable LSD radix sort over the
         // cost's bit pattern (costs are >= 0, so bit order is numeric order) with the point index
@@ -1161,6 +1193,12 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     ICPX_HIP(hipMemcpyAsync(lg->guess.p, guess, sizeof(double) * (D + 1) * (D + 1), hipMemcpyDefault, lg->stream));
     // c = a (vanilla_3d.cpp:72): the guess is NOT applied to the running cloud (Q5)
     ICPX_HIP(hipMemcpyAsync(lg->cur.p, lg->src.p, sizeof(double) * D * n, hipMemcpyDeviceToDevice, lg->stream));
+    if (D == 3 && (lg->prm.flags & ICPX_FLAG_APPLY_GUESS)) {
+        // opt-in correction of Q5: c = guess * a
+        hipLaunchKernelGGL(lg_apply_guess_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, lg->stream,
+                           lg->guess.as<double>(), lg->src.as<double>(), lg->cur.as<double>(), n);
+        ICPX_HIP(hipGetLastError());
+    }
     ICPX_HIP(hipMemsetAsync(lg->sel.p, 1, n, lg->stream));
     lg->sorted = false;
     lg->feature = D == 2 && lg->method == ICPX_FEATURE_AWARE;
@@ -1282,7 +1320,7 @@ int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost) {
     // 2D only (3D is answered by the caller).  Vanilla: point order.  Trimmed: point order after
     // begin, the sorted order Trimmed::iterate leaves behind (trimmed.cpp:55-56) afterwards.
     const int64_t n = lg->n;
-    const bool by_order = lg->method != ICPX_VANILLA && lg->sorted;
+    const bool by_order = lg->dim == 2 && lg->method != ICPX_VANILLA && lg->sorted;
     DevBuf tp, tq, tc;
     int rc = tp.reserve(sizeof(int64_t) * n);
     if (rc == ICPX_OK) rc = tq.reserve(sizeof(int64_t) * n);

@@ -23,6 +23,9 @@ namespace icp {
             p.feature_weight = config.get<double>("feature_weight", p.feature_weight);                // feature_aware.cpp:40
             p.symmetric_neighbors = config.get<int>("symmetric_neighbors", p.symmetric_neighbors);    // feature_aware.cpp:41
             // optional, non-reference keys
+            p.flags = (config.get<int>("match_transformed", 0) ? ICPX_FLAG_MATCH_TRANSFORMED : 0) |
+                      (config.get<int>("fill_matches", 0) ? ICPX_FLAG_FILL_MATCHES : 0) |
+                      (config.get<int>("apply_guess", 0) ? ICPX_FLAG_APPLY_GUESS : 0);
             p.device = config.get<int>("device", -1);
             const std::string nn = config.get<std::string>("nn", "auto");
             p.nn_mode = nn == "brute" ? ICPX_NN_BRUTE : nn == "grid" ? ICPX_NN_GRID : ICPX_NN_AUTO;

@@ -63,6 +63,15 @@ enum icpx_nn_mode {
     ICPX_NN_GRID = 2   /* exact uniform-grid search                                 */
 };
 
+/* Opt-in corrections of reference quirks (§8 f4).  NOT reference behaviour:
+ * no counterpart in cornellev/icp; defaults (0) keep parity.  Handles only; such handles run on the
+ * multi-kernel path. */
+enum icpx_flags {
+    ICPX_FLAG_MATCH_TRANSFORMED = 1, /* Vanilla (2D): match transform*a, every iteration, instead of a once (vanilla.cpp:80) */
+    ICPX_FLAG_FILL_MATCHES = 2,      /* 3D methods: fill `matches` (point, neighbour, distance) in setup and iterate, so calculate_cost works */
+    ICPX_FLAG_APPLY_GUESS = 4        /* 3D methods: the running cloud starts as guess*a (vanilla_3d.cpp:72 starts from a) */
+};
+
 /* What icp::Config carries for these methods (include/icp/config.h) plus placement. */
 typedef struct icpx_params {
     double overlap_rate; /* Config "overlap_rate" — Trimmed(2D), trimmed.cpp:28, default 0.9   */
@@ -72,7 +81,7 @@ typedef struct icpx_params {
     void* stream;        /* hipStream_t to run on; NULL = the null stream                       */
     double feature_weight;       /* Config "feature_weight" — FeatureAware, feature_aware.cpp:23, default 0.7      */
     int32_t symmetric_neighbors; /* Config "symmetric_neighbors" — FeatureAware, feature_aware.cpp:24, default 10 */
-    int32_t reserved;            /* 0 */
+    int32_t flags;               /* enum icpx_flags; 0 = the reference's behaviour */
 } icpx_params;
 
 /* ICPDriver's optional termination criteria (include/icp/driver.h:80-151, 226-233). */

@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 VANILLA, TRIMMED, FEATURE_AWARE = 0, 1, 2
+FLAG_MATCH_TRANSFORMED, FLAG_FILL_MATCHES, FLAG_APPLY_GUESS = 1, 2, 4
 NN_KDTREE, NN_BRUTE = 0, 1
 SUM_SEQUENTIAL, SUM_TREE64 = 0, 1
 
@@ -25,7 +26,7 @@ HAS_ABS_TOL, HAS_TRANSFORM_TOL, HAS_TIME_LIMIT = 16, 32, 64
 class Params(C.Structure):
     _fields_ = [("overlap_rate", C.c_double), ("max_distance", C.c_double),
                 ("nn_mode", C.c_int32), ("sum_mode", C.c_int32),
-                ("feature_weight", C.c_double), ("symmetric_neighbors", C.c_int32), ("_pad", C.c_int32)]
+                ("feature_weight", C.c_double), ("symmetric_neighbors", C.c_int32), ("flags", C.c_int32)]
 
 
 class Criteria(C.Structure):
@@ -218,10 +219,10 @@ class OracleICP:
     """Mirror of icp::ICP<Dim> (icp.h) + ICPDriver::converge (driver.h) on the CPU oracle."""
 
     def __init__(self, dim, method, overlap_rate=0.9, max_distance=1.0, nn_mode=NN_KDTREE,
-                 sum_mode=SUM_SEQUENTIAL, feature_weight=0.7, symmetric_neighbors=10):
+                 sum_mode=SUM_SEQUENTIAL, feature_weight=0.7, symmetric_neighbors=10, flags=0):
         self.dim = dim
         self.method = {"vanilla": VANILLA, "trimmed": TRIMMED, "feature_aware": FEATURE_AWARE}.get(method, method)
-        p = Params(overlap_rate, max_distance, nn_mode, sum_mode, feature_weight, symmetric_neighbors, 0)
+        p = Params(overlap_rate, max_distance, nn_mode, sum_mode, feature_weight, symmetric_neighbors, flags)
         self._h = lib().orc_create(dim, self.method, C.byref(p))
         assert self._h
         self.n = 0

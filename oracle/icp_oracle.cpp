@@ -615,7 +615,15 @@ struct Icp : IcpBase {
         } else {
             // vanilla_3d.cpp:71-81, trimmed_3d.cpp:77-87: c = a (guess NOT applied), build tree once
             cur = a;
+            if (prm.flags & ORC_FLAG_APPLY_GUESS) apply_transform_to(a, cur, transform);  // opt-in, fixes Q5
             if (prm.nn_mode == ORC_NN_KDTREE) kdtree.build(b.data(), m);
+            if ((prm.flags & ORC_FLAG_FILL_MATCHES) && n > 0 && m > 0) {  // opt-in, fixes Q4
+                nn_tree_or_brute(cur, false, nb_idx, nb_dist);
+                for (int64_t i = 0; i < n; i++) {
+                    nb_dist[i] = std::sqrt(nb_dist[i]);
+                    matches[i] = Match{i, nb_idx[i], nb_dist[i]};
+                }
+            }
         }
     }
 
@@ -625,7 +633,8 @@ struct Icp : IcpBase {
             if (n == 0 || m == 0) return;
             std::vector<int64_t> idx;
             std::vector<double> dist;
-            nn_tree_or_brute(a, true, idx, dist);
+            // Q1: the reference queries the UNTRANSFORMED cloud; the opt-in correction queries a_current
+            nn_tree_or_brute((prm.flags & ORC_FLAG_MATCH_TRANSFORMED) ? cur : a, true, idx, dist);
             for (int64_t i = 0; i < n; i++) {
                 matches[i].cost = std::sqrt(dist[i]);  // vanilla.cpp:84 sqrt of an Euclidean distance
                 matches[i].point = i;
@@ -749,6 +758,8 @@ struct Icp : IcpBase {
     void iterate_3d() {
         nn_tree_or_brute(cur, false, nb_idx, nb_dist);
         for (int64_t i = 0; i < n; i++) nb_dist[i] = std::sqrt(nb_dist[i]);  // vanilla_3d.cpp:41
+        if (prm.flags & ORC_FLAG_FILL_MATCHES)
+            for (int64_t i = 0; i < n; i++) matches[i] = Match{i, nb_idx[i], nb_dist[i]};
         Xf<D> T;
         if (prm.sum_mode == ORC_SUM_SEQUENTIAL) {
             std::vector<int64_t> si, di;

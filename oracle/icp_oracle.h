@@ -55,8 +55,15 @@ typedef struct {
     int32_t sum_mode;    /* ORC_SUM_* */
     double feature_weight;       /* FeatureAware: feature_aware.cpp:23, default 0.7 */
     int32_t symmetric_neighbors; /* FeatureAware: feature_aware.cpp:24, default 10  */
-    int32_t _pad;
+    int32_t flags;               /* ORC_FLAG_*: opt-in corrections of reference quirks; 0 = reference behaviour */
 } orc_params;
+
+/* "corrected" modes — NOT reference behaviour, defined by this restatement */
+enum {
+    ORC_FLAG_MATCH_TRANSFORMED = 1, /* Vanilla (2D): match transform*a instead of a, every iteration (fixes Q1) */
+    ORC_FLAG_FILL_MATCHES = 2,      /* 3D methods: fill `matches` (point, neighbour, distance) in setup and in every iterate, so calculate_cost is meaningful (fixes Q4) */
+    ORC_FLAG_APPLY_GUESS = 4        /* 3D methods: the running cloud starts as guess*a (fixes Q5) */
+};
 
 /* driver.h:226-233 — one optional per criterion */
 enum {

@@ -461,6 +461,56 @@ def test_feature_aware_matches_oracle(icp, ob, scans):
     assert icp.ICP3.from_method("feature_aware") is None  # registered for ICP2 only (lib/icp/icp.cpp:17-27)
 
 
+def test_corrected_modes_match_oracle(icp, ob, scans):
+    """the opt-in corrections of reference quirks (Config keys match_transformed /
+    fill_matches / apply_guess; NOT reference behaviour, defined by the oracle) — bit-exact against
+    the oracle run with the same flags, and the defaults untouched."""
+    from icp_amd import synth
+    # Q1: vanilla ICP2 matching transform*a in every iteration
+    for k, (a, b) in scans.items():
+        cfg = icp.Config()
+        cfg.set("match_transformed", 1)
+        d = driver(icp, icp.ICP2, "vanilla", BENCH_CRIT, cfg)
+        r = d.converge(a, b)
+        o = dev_oracle(ob, 2, "vanilla", flags=ob.FLAG_MATCH_TRANSFORMED)
+        ro = o.converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
+        assert r.iteration_count == ro.iteration_count and r.iteration_count > 2, k
+        assert np.array_equal(r.transform, ro.transform) and r.cost == ro.cost, k
+        for u, v in zip(d.icp_.get_matches_arrays(), o.get_matches()):
+            assert np.array_equal(u, v), k
+    # Q4 / Q5: 3D methods filling matches and starting from guess*a
+    s, t, _, _ = synth.config5_pairs([12], 3, 1500)
+    g = np.eye(4)
+    g[:3, 3] = (0.08, -0.05, 0.03)
+    crit = dict(max_iterations=25, transform_tol=(1e-6, 1e-6))
+    for method in ("vanilla", "trimmed"):
+        for fill, guess in ((1, 0), (0, 1), (1, 1)):
+            cfg = icp.Config()
+            cfg.set("fill_matches", fill)
+            cfg.set("apply_guess", guess)
+            cfg.set("max_distance", 0.5)
+            flags = (ob.FLAG_FILL_MATCHES if fill else 0) | (ob.FLAG_APPLY_GUESS if guess else 0)
+            x = icp.ICP3.from_method(method, cfg)
+            o = dev_oracle(ob, 3, method, max_distance=0.5, flags=flags)
+            x.begin(s, t, g)
+            o.begin(s, t, g)
+            assert x.calculate_cost() == o.calculate_cost(), (method, fill, guess)
+            for it in range(3):
+                x.iterate()
+                o.iterate()
+                assert np.array_equal(x.current_transform(), o.current_transform()), (method, fill, guess, it)
+                assert x.calculate_cost() == o.calculate_cost(), (method, fill, guess, it)
+                for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+                    assert np.array_equal(u, v), (method, fill, guess, it)
+            if fill:
+                assert x.calculate_cost() > 0.0
+            d = driver(icp, icp.ICP3, method, crit, cfg)
+            r = d.converge(s, t, g)
+            ro = o.converge(s, t, g, ob.make_criteria(**crit))
+            assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
+            assert r.cost == ro.cost
+
+
 def test_driver_criteria_on_device(icp, ob, scans):
     a, b = scans[1]
     for crit in [dict(max_iterations=5), dict(max_iterations=0), dict(min_iterations=7, max_iterations=50, stop_cost=1e9),
