@@ -174,7 +174,10 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
 // split), seedless otherwise.  Per-split results are merged by lg_tile_merge_kernel in the (d2, index)
 // order.  On 256 CUs this beats the grid walk up to about 3e4 x 3e4 points.
 constexpr int kTileThreads = 256;
-constexpr int kTileQpt = 4;
+#ifndef ICPX_TILE_QPT
+#define ICPX_TILE_QPT 4
+#endif
+constexpr int kTileQpt = ICPX_TILE_QPT;
 constexpr int kTileQueries = kTileThreads * kTileQpt;
 constexpr int kTileScratch = 96;  // doubles of reduction scratch
 constexpr int kTileMaxSplit = 3072;  // targets per split at most (3D: 110 KB of LDS)
@@ -246,10 +249,10 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     float* f = reinterpret_cast<float*>(p);
     for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
     L.j0 = static_cast<int>(t0);
-    const FilterFrame F = stage_targets<D>(dst + t0 * D, mt, m4, kTileThreads, L, true);
-
+    // queries and seed indices first: their loads are in flight while the split is staged
     double q[kTileQpt][D], best[kTileQpt];
     int bidx[kTileQpt];
+    int64_t seed[kTileQpt];
     const int64_t qbase = static_cast<int64_t>(blockIdx.x) * kTileQueries;
     const bool seeded = dev->nn_valid != 0;
     XfRows<D> xr;
@@ -272,12 +275,17 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
 #pragma unroll
             for (int d = 0; d < D; d++) q[k][d] = pnt[d];
         }
+        int64_t j = (seeded && valid) ? nb_idx[i] : 0;
+        seed[k] = j < 0 ? 0 : (j >= m ? m - 1 : j);
+    }
+    const FilterFrame F = stage_targets<D>(dst + t0 * D, mt, m4, kTileThreads, L, true);
+#pragma unroll
+    for (int k = 0; k < kTileQpt; k++) {
         best[k] = __builtin_inf();
         bidx[k] = 0x7fffffff;
         if (seeded) {
             // exact distance to the previous neighbour: an upper bound for every split
-            int64_t j = valid ? nb_idx[i] : 0;
-            j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+            const int64_t j = seed[k];
             double df = dst[j * D + 0] - q[k][0];
             double acc = df * df;
 #pragma unroll
@@ -350,21 +358,26 @@ ICPX_DEV void block_tree(F&& f, int64_t n, double* __restrict__ part, int nblk, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
     const int64_t g_total = (n + 63) >> 6;
+    // gather the terms of all four slots first: their (dependent) global loads overlap instead of
+    // paying one round trip per slot
+    double vals[kSlots][NV];
 #pragma unroll
     for (int k = 0; k < kSlots; k++) {
         int64_t i = base + k * kBlk + tid;
+        if (i < n) {
+            f(i, vals[k]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) vals[k][v] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
         int64_t g = (base >> 6) + k * (kBlk >> 6) + wave;
         if (g < g_total) {
-            double vals[NV];
-            if (i < n) {
-                f(i, vals);
-            } else {
-#pragma unroll
-                for (int v = 0; v < NV; v++) vals[v] = 0.0;
-            }
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                double s = wave_sum(vals[v]);
+                double s = wave_sum(vals[k][v]);
                 if (lane == 0) gs[v * 64 + k * (kBlk >> 6) + wave] = s;
             }
         }
