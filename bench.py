@@ -243,6 +243,36 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
     dt = (time.perf_counter() - t0) / 5
     ex["c4_grid_nn_1m_build_plus_query_ms"] = dt * 1e3
     ex["c4_grid_nn_1m_queries_per_s"] = len(src) / dt
+    # SURVEY 8(d) roofline of the grid query (HBM/L2-bound): algorithmic bytes per query = 8*D (query)
+    # + 32 * c_bar (32-byte target records examined, counted by the kernel) + 16 (int64 index + f64 d2)
+    import ctypes as C
+    prof = (C.c_double * 4)()
+    lib = icp_amd._lib.load()
+    best = None
+    for _ in range(3):
+        icp_amd._lib.check(lib.icpx_nn_grid_profile(3, d_q.data_ptr(), len(src), d_t.data_ptr(), len(tgt),
+                                                    local_rank, stream, prof))
+        if best is None or prof[1] < best[1]:
+            best = list(prof)
+    bytes_per_query = 8 * 3 + 32 * best[2] + 16
+    gbps = bytes_per_query * len(src) / (best[1] * 1e-3) / 1e9
+    ex["c4_grid"] = {"build_ms": best[0], "query_ms": best[1], "candidates_per_query": best[2],
+                     "cells": int(best[3]), "algorithmic_bytes_per_query": bytes_per_query,
+                     "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": gbps / 8000.0}}
+    # config 4, M2: full converge of the 1 M x 1 M pair (vanilla ICP3, max 50 iterations, tol 1e-4)
+    drv4 = icp_amd.ICPDriver(icp_amd.ICP3.from_method("vanilla", device=local_rank))
+    drv4.set_max_iterations(MAX_ITER)
+    drv4.set_transform_tolerance(*TOL)
+    r4 = drv4.converge(d_q, d_t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r4 = drv4.converge(d_q, d_t)
+    torch.cuda.synchronize()
+    dt4 = time.perf_counter() - t0
+    ex["c4_converge_ms"] = dt4 * 1e3
+    ex["c4_converge_iterations"] = r4.iteration_count
+    ex["c4_converge_queries_per_s"] = r4.iteration_count * len(src) / dt4
     return ex
 
 

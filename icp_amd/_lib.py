@@ -48,6 +48,7 @@ SYMBOLS = [
     "icpx_init", "icpx_version", "icpx_last_error", "icpx_default_params", "icpx_create",
     "icpx_destroy", "icpx_begin", "icpx_iterate", "icpx_cost", "icpx_transform", "icpx_matches",
     "icpx_sizes", "icpx_debug_neighbors", "icpx_converge", "icpx_converge_batch", "icpx_nn",
+    "icpx_nn_grid_profile",
 ]
 
 _lib = None
@@ -80,6 +81,7 @@ def load():
     L.icpx_debug_neighbors.argtypes = [_vp, _vp, _vp]
     L.icpx_converge.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.POINTER(Criteria),
                                 C.POINTER(State)]
+    L.icpx_nn_grid_profile.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp, C.POINTER(C.c_double)]
     L.icpx_converge_batch.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.c_int64, _vp, _vp,
                                       _vp, _vp, _vp, C.POINTER(Criteria), _vp]
     L.icpx_nn.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int, _vp]

@@ -667,6 +667,22 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
     return ICPX_OK;
 }
 
+int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+                         int device, void* stream_, double* out) {
+    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (n <= 0 || m <= 0 || !queries || !targets || !out) return fail(ICPX_ERR_INVALID, "null or empty input");
+    if (n > INT32_MAX / 4 || m > INT32_MAX / 4) return fail(ICPX_ERR_UNSUPPORTED, "cloud too large");
+    int dev = 0;
+    ICPX_TRY(resolve_device(device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    if (!is_device_ptr(queries) || !is_device_ptr(targets))
+        return fail(ICPX_ERR_INVALID, "icpx_nn_grid_profile takes device pointers");
+    return grid_profile(dim, queries, n, targets, m, static_cast<hipStream_t>(stream_), out);
+}
+
 #ifdef ICPX_STATS
 // development builds only (-DICPX_STATS): read / reset the kernel statistics counters
 int icpx_debug_stats(unsigned long long* out, int reset) {

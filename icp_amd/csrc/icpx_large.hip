@@ -928,6 +928,44 @@ int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t*
     return ICPX_OK;
 }
 
+int grid_profile(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, hipStream_t stream, double* out) {
+    GridIndex* g = nullptr;
+    ICPX_TRY(grid_create(&g));
+    DevBuf visited;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int rc = visited.reserve(sizeof(unsigned long long));
+    for (int i = 0; i < 3 && rc == ICPX_OK; i++)
+        if (hipEventCreate(&ev[i]) != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipEventCreate failed");
+    auto hip = [&](hipError_t e, const char* what) {
+        if (rc == ICPX_OK && e != hipSuccess) rc = fail(ICPX_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    if (rc == ICPX_OK) {
+        hip(hipMemsetAsync(visited.p, 0, sizeof(unsigned long long), stream), "hipMemsetAsync");
+        hip(hipEventRecord(ev[0], stream), "hipEventRecord");
+        if (rc == ICPX_OK) rc = grid_build(g, dim, d_t, m, stream);
+        hip(hipEventRecord(ev[1], stream), "hipEventRecord");
+        if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, nullptr, nullptr, visited.as<unsigned long long>(), stream);
+        hip(hipEventRecord(ev[2], stream), "hipEventRecord");
+        hip(hipEventSynchronize(ev[2]), "hipEventSynchronize");
+    }
+    if (rc == ICPX_OK) {
+        float b = 0.f, q = 0.f;
+        unsigned long long v = 0;
+        hip(hipEventElapsedTime(&b, ev[0], ev[1]), "hipEventElapsedTime");
+        hip(hipEventElapsedTime(&q, ev[1], ev[2]), "hipEventElapsedTime");
+        hip(hipMemcpy(&v, visited.p, sizeof(v), hipMemcpyDeviceToHost), "hipMemcpy");
+        out[0] = b;
+        out[1] = q;
+        out[2] = n > 0 ? static_cast<double>(v) / static_cast<double>(n) : 0.0;
+        out[3] = static_cast<double>(g->ncell);
+    }
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    visited.release();
+    grid_destroy(g);
+    return rc;
+}
+
 int grid_nn_oneshot(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
                     double* d_d2, hipStream_t stream) {
     GridIndex* g = nullptr;

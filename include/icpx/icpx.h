@@ -189,6 +189,13 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
                         const double* guesses, const icpx_criteria* criteria,
                         icpx_state* out_states);
 
+/* Measurement helper (no counterpart in the reference): one build + one query of the uniform-grid
+ * search with device-memory inputs (queries, targets must be device pointers), timed with HIP
+ * events on `stream`.  out[0] = build ms, out[1] = query ms, out[2] = mean number of target records
+ * a query examined (the c-bar of SURVEY 8(d)'s bytes-per-query figure), out[3] = grid cells. */
+int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+                         int device, void* stream, double* out);
+
 /* Stand-alone correspondence query: the arithmetic of Trimmed::compute_matches
  * (trimmed.cpp:95-109) / KdTree::search (kdtree.h:79-89) under the documented tie-break.
  * idx: n x int64 target indices; d2: n x f64 squared distances (either may be NULL).
