@@ -218,6 +218,7 @@ icpx_criteria no_criteria() {
 struct Workspace {
     std::mutex mu;
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
+    GridIndex* grid = nullptr;  // grow-only uniform-grid index of the stand-alone queries
 };
 Workspace& workspace(int device) {
     static std::mutex mu;
@@ -680,7 +681,10 @@ int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double
     ICPX_TRY(device_info(dev, &di));
     if (!is_device_ptr(queries) || !is_device_ptr(targets))
         return fail(ICPX_ERR_INVALID, "icpx_nn_grid_profile takes device pointers");
-    return grid_profile(dim, queries, n, targets, m, static_cast<hipStream_t>(stream_), out);
+    Workspace& ws = workspace(dev);
+    std::lock_guard<std::mutex> lk(ws.mu);
+    if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
+    return grid_profile(ws.grid, dim, queries, n, targets, m, static_cast<hipStream_t>(stream_), out);
 }
 
 #ifdef ICPX_STATS
@@ -742,7 +746,8 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
                     (mode == ICPX_NN_AUTO && static_cast<double>(n) * static_cast<double>(m) > 64.0 * 1024 * 1024);
     if (m == 0) use_grid = false;
     if (use_grid) {
-        ICPX_TRY(grid_nn_oneshot(dim, d_q, n, d_t, m, d_idx, d_d2, stream));
+        if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
+        ICPX_TRY(grid_nn_oneshot(ws.grid, dim, d_q, n, d_t, m, d_idx, d_d2, stream));
     } else {
         // (query blocks) x (target splits) so that the launch fills the chip
         const int qblocks = static_cast<int>((n + kNnThreads * kNnQpt - 1) / (kNnThreads * kNnQpt));

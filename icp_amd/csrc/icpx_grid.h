@@ -339,10 +339,14 @@ template <int D>
 __global__ void __launch_bounds__(256)
 grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const GridRec* __restrict__ recs,
                const int* __restrict__ start, int64_t* __restrict__ idx, double* __restrict__ d2,
-               unsigned long long* __restrict__ visited_total) {
+               unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm) {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     int visited = 0;
-    if (i < n) {
+    const bool live = i < n;
+    // queries are visited in cell order (perm, grid_sort_queries) so that neighbouring lanes walk the
+    // same cells: 1.6x on 1 M random queries
+    if (live && perm) i = perm[i];
+    if (live) {
         double qq[D];
 #pragma unroll
         for (int d = 0; d < D; d++) qq[d] = q[i * D + d];
@@ -356,6 +360,19 @@ grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const Gri
         int v = wave_sum_int(visited);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(visited_total, static_cast<unsigned long long>(v));
     }
+}
+
+// cell of every query (clamped into the grid) as the sort key of grid_sort_queries
+template <int D>
+__global__ void grid_query_keys_kernel(const double* __restrict__ q, int64_t n, GridParams gp,
+                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ iota) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double p[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) p[d] = q[i * D + d];
+    keys[i] = static_cast<uint32_t>(cell_of<D>(gp, p));
+    iota[i] = static_cast<uint32_t>(i);
 }
 
 }  // namespace icpx

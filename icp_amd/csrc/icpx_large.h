@@ -36,8 +36,8 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
 // accumulates the number of candidate targets examined.
 int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
                       unsigned long long* d_visited, hipStream_t stream);
-int grid_profile(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, hipStream_t stream, double* out);
-int grid_nn_oneshot(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m,
+int grid_profile(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, hipStream_t stream, double* out);
+int grid_nn_oneshot(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m,
                     int64_t* d_idx, double* d_d2, hipStream_t stream);
 
 }  // namespace icpx

@@ -41,6 +41,9 @@ struct GridIndex {
     int dim = 0;
     int ncell = 0;
     DevBuf recs, start, cell_id, counts, keys, totals;
+    // query order by cell (grid_sort_queries); q_perm_n == 0: none
+    DevBuf q_keys, q_keys_out, q_iota, q_perm, q_tmp;
+    int64_t q_perm_n = 0;
 };
 
 struct LargeDev {
@@ -124,10 +127,11 @@ __global__ void __launch_bounds__(256)
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
-             double max_distance) {
+             double max_distance, const uint32_t* __restrict__ perm) {
     if (respect_done && dev->st.done) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (perm) i = perm[i];  // cell order of the initial cloud: neighbouring lanes walk the same cells
     double q[D];
     if (MODE == 1) {
 #pragma unroll
@@ -173,6 +177,7 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
 // previous step's neighbour when there is one (whose exact distance bounds the answer for EVERY
 // split), seedless otherwise.  Per-split results are merged by lg_tile_merge_kernel in the (d2, index)
 // order.  On 256 CUs this beats the grid walk up to about 3e4 x 3e4 points.
+constexpr int64_t kGridSortMinQueries = 32768;
 constexpr int kTileThreads = 256;
 #ifndef ICPX_TILE_QPT
 #define ICPX_TILE_QPT 4
@@ -792,7 +797,9 @@ int grid_create(GridIndex** out) {
 
 void grid_destroy(GridIndex* g) {
     if (!g) return;
-    for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys, &g->totals}) b->release();
+    for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys, &g->totals, &g->q_keys, &g->q_keys_out,
+                      &g->q_iota, &g->q_perm, &g->q_tmp})
+        b->release();
     delete g;
 }
 
@@ -914,23 +921,54 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
     return ICPX_OK;
 }
 
+// Orders the queries by the grid cell they fall in (stable radix sort of the cell ids): the query
+// kernels then visit them in that order.  Worth it from a few 10^4 queries on.
+int grid_sort_queries(GridIndex* g, const double* d_q, int64_t n, hipStream_t stream) {
+    g->q_perm_n = 0;
+    if (n < kGridSortMinQueries || g->gp.m <= 0) return ICPX_OK;
+    ICPX_TRY(g->q_keys.reserve(sizeof(uint32_t) * n));
+    ICPX_TRY(g->q_keys_out.reserve(sizeof(uint32_t) * n));
+    ICPX_TRY(g->q_iota.reserve(sizeof(uint32_t) * n));
+    ICPX_TRY(g->q_perm.reserve(sizeof(uint32_t) * n));
+    const unsigned nb = static_cast<unsigned>((n + 255) / 256);
+    if (g->dim == 2)
+        hipLaunchKernelGGL(grid_query_keys_kernel<2>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp,
+                           g->q_keys.as<uint32_t>(), g->q_iota.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(grid_query_keys_kernel<3>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp,
+                           g->q_keys.as<uint32_t>(), g->q_iota.as<uint32_t>());
+    ICPX_HIP(hipGetLastError());
+    int bits = 1;
+    while (bits < 32 && (int64_t(1) << bits) < g->ncell) bits++;
+    size_t bytes = 0;
+    ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, g->q_keys.as<uint32_t>(), g->q_keys_out.as<uint32_t>(),
+                                                g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(), static_cast<int>(n), 0,
+                                                bits, stream));
+    ICPX_TRY(g->q_tmp.reserve(bytes ? bytes : 1));
+    ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(g->q_tmp.p, bytes, g->q_keys.as<uint32_t>(), g->q_keys_out.as<uint32_t>(),
+                                                g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(), static_cast<int>(n), 0,
+                                                bits, stream));
+    g->q_perm_n = n;
+    return ICPX_OK;
+}
+
 int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
                       unsigned long long* d_visited, hipStream_t stream) {
     if (n <= 0) return ICPX_OK;
     unsigned nb = static_cast<unsigned>((n + 255) / 256);
+    const uint32_t* perm = g->q_perm_n == n ? g->q_perm.as<uint32_t>() : nullptr;
     if (g->dim == 2)
         hipLaunchKernelGGL(grid_nn_kernel<2>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
-                           g->start.as<int>(), d_idx, d_d2, d_visited);
+                           g->start.as<int>(), d_idx, d_d2, d_visited, perm);
     else
         hipLaunchKernelGGL(grid_nn_kernel<3>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
-                           g->start.as<int>(), d_idx, d_d2, d_visited);
+                           g->start.as<int>(), d_idx, d_d2, d_visited, perm);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
 
-int grid_profile(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, hipStream_t stream, double* out) {
-    GridIndex* g = nullptr;
-    ICPX_TRY(grid_create(&g));
+int grid_profile(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, hipStream_t stream,
+                 double* out) {
     DevBuf visited;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int rc = visited.reserve(sizeof(unsigned long long));
@@ -944,6 +982,7 @@ int grid_profile(int dim, const double* d_q, int64_t n, const double* d_t, int64
         hip(hipEventRecord(ev[0], stream), "hipEventRecord");
         if (rc == ICPX_OK) rc = grid_build(g, dim, d_t, m, stream);
         hip(hipEventRecord(ev[1], stream), "hipEventRecord");
+        if (rc == ICPX_OK) rc = grid_sort_queries(g, d_q, n, stream);
         if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, nullptr, nullptr, visited.as<unsigned long long>(), stream);
         hip(hipEventRecord(ev[2], stream), "hipEventRecord");
         hip(hipEventSynchronize(ev[2]), "hipEventSynchronize");
@@ -962,21 +1001,18 @@ int grid_profile(int dim, const double* d_q, int64_t n, const double* d_t, int64
     for (hipEvent_t e : ev)
         if (e) (void)hipEventDestroy(e);
     visited.release();
-    grid_destroy(g);
     return rc;
 }
 
-int grid_nn_oneshot(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
+int grid_nn_oneshot(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
                     double* d_d2, hipStream_t stream) {
-    GridIndex* g = nullptr;
-    ICPX_TRY(grid_create(&g));
     int rc = grid_build(g, dim, d_t, m, stream);
+    if (rc == ICPX_OK) rc = grid_sort_queries(g, d_q, n, stream);
     if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, d_idx, d_d2, nullptr, stream);
     if (rc == ICPX_OK) {
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
-    grid_destroy(g);
     return rc;
 }
 
@@ -1117,7 +1153,8 @@ int enqueue_nn(LargeIcp* lg, int respect) {
         hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
                            lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
-                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance,
+                           lg->grid->q_perm_n == lg->n ? lg->grid->q_perm.as<uint32_t>() : nullptr);
         ICPX_HIP(hipGetLastError());
         return ICPX_OK;
     }
@@ -1291,6 +1328,8 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         ICPX_TRY(lg->part_idx.reserve(sizeof(int32_t) * static_cast<size_t>(splits) * n));
     } else {
         ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
+        // the running cloud moves little between iterations: its initial cell order stays coherent
+        ICPX_TRY(grid_sort_queries(lg->grid, lg->cur.as<double>(), n, lg->stream));
     }
     if (lg->feature) {
         // the reference keeps the dense n x m feature-distance matrix too (feature_aware.h:60)
