@@ -749,25 +749,63 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
         if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
         ICPX_TRY(grid_nn_oneshot(ws.grid, dim, d_q, n, d_t, m, d_idx, d_d2, stream));
     } else {
-        // (query blocks) x (target splits) so that the launch fills the chip
-        const int qblocks = static_cast<int>((n + kNnThreads * kNnQpt - 1) / (kNnThreads * kNnQpt));
+        // (query tiles) x (target splits) so that the launch fills the chip; f32 filter + exact
+        // refinement (nn_tile_kernel).  ICPX_FILTER=0 (development) selects the plain f64 kernel.
+        const char* fe = std::getenv("ICPX_FILTER");
+        const bool plain = fe && fe[0] == '0';
+        const int per_tile = plain ? kNnThreads * kNnQpt : kNnThreads * kNnTileQpt;
+        const int qblocks = static_cast<int>((n + per_tile - 1) / per_tile);
         int splits = (4 * di->cus + qblocks - 1) / qblocks;
-        int max_splits = static_cast<int>((m + kNnTile - 1) / kNnTile);
+        const int64_t min_len = plain ? kNnTile : kNnMinSplit;
+        int max_splits = static_cast<int>((m + min_len - 1) / min_len);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         int64_t split_len = (m + splits - 1) / splits;
-        split_len = (split_len + kNnTile - 1) / kNnTile * kNnTile;
-        if (split_len < kNnTile) split_len = kNnTile;
+        if (plain) {
+            split_len = (split_len + kNnTile - 1) / kNnTile * kNnTile;
+            if (split_len < kNnTile) split_len = kNnTile;
+        } else {
+            split_len = (split_len + 3) & ~int64_t(3);
+            if (split_len < 4) split_len = 4;
+            if (split_len > kNnMaxSplit) split_len = kNnMaxSplit;
+        }
         splits = m > 0 ? static_cast<int>((m + split_len - 1) / split_len) : 1;
+        if (splits > 65535) return fail(ICPX_ERR_UNSUPPORTED, "target cloud too large for the brute-force search; use the grid");
         ICPX_TRY(ws.part_d2.reserve(sizeof(double) * n * splits));
         ICPX_TRY(ws.part_idx.reserve(sizeof(int32_t) * n * splits));
         dim3 grid(qblocks, splits);
-        if (dim == 2)
-            hipLaunchKernelGGL(nn_brute_kernel<2>, grid, dim3(kNnThreads), 0, stream, d_q, n, d_t, m, split_len,
-                               ws.part_d2.as<double>(), ws.part_idx.as<int32_t>());
-        else
-            hipLaunchKernelGGL(nn_brute_kernel<3>, grid, dim3(kNnThreads), 0, stream, d_q, n, d_t, m, split_len,
-                               ws.part_d2.as<double>(), ws.part_idx.as<int32_t>());
+        if (plain) {
+            if (dim == 2)
+                hipLaunchKernelGGL(nn_brute_kernel<2>, grid, dim3(kNnThreads), 0, stream, d_q, n, d_t, m, split_len,
+                                   ws.part_d2.as<double>(), ws.part_idx.as<int32_t>());
+            else
+                hipLaunchKernelGGL(nn_brute_kernel<3>, grid, dim3(kNnThreads), 0, stream, d_q, n, d_t, m, split_len,
+                                   ws.part_d2.as<double>(), ws.part_idx.as<int32_t>());
+        } else {
+            const size_t lds = nn_tile_lds_bytes(dim, static_cast<int>(split_len));
+            static std::mutex amu;
+            static std::unordered_map<int, bool> aset;
+            {
+                std::lock_guard<std::mutex> alk(amu);
+                if (!aset[dev]) {
+                    ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nn_tile_kernel<2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(nn_tile_lds_bytes(3, kNnMaxSplit))));
+                    ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nn_tile_kernel<3>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(nn_tile_lds_bytes(3, kNnMaxSplit))));
+                    aset[dev] = true;
+                }
+            }
+            if (dim == 2)
+                hipLaunchKernelGGL(nn_tile_kernel<2>, grid, dim3(kNnThreads), lds, stream, d_q, n, d_t, m,
+                                   static_cast<int>(split_len), static_cast<int>(split_len), ws.part_d2.as<double>(),
+                                   ws.part_idx.as<int32_t>());
+            else
+                hipLaunchKernelGGL(nn_tile_kernel<3>, grid, dim3(kNnThreads), lds, stream, d_q, n, d_t, m,
+                                   static_cast<int>(split_len), static_cast<int>(split_len), ws.part_d2.as<double>(),
+                                   ws.part_idx.as<int32_t>());
+        }
         ICPX_HIP(hipGetLastError());
         hipLaunchKernelGGL(nn_merge_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, n,
                            splits, ws.part_d2.as<double>(), ws.part_idx.as<int32_t>(), d_idx, d_d2);

@@ -6,6 +6,7 @@
 //  * uniform-grid search (build + query) for large clouds: icpx_grid.h.
 #pragma once
 
+#include "icpx_filter.h"
 #include "icpx_math.h"
 
 namespace icpx {
@@ -101,6 +102,65 @@ nn_brute_kernel(const double* __restrict__ q, int64_t n, const double* __restric
         if (i < n) {
             part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = best[k];
             part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = bidx[k];
+        }
+    }
+}
+
+// The same search through the f32 candidate filter with exact f64 refinement (icpx_filter.h):
+// grid = (query tiles of 1024, target splits); every workgroup stages its split in LDS and runs the
+// seedless two-minimum pass.  Results are those of nn_brute_kernel, bit for bit, at about a third
+// of the VALU work.  LDS: (8 + 4) * D * scap bytes + kNnScratch doubles.
+constexpr int kNnTileQpt = 4;
+constexpr int kNnScratch = 96;
+constexpr int kNnMaxSplit = 3072;
+constexpr int kNnMinSplit = 256;
+
+inline size_t nn_tile_lds_bytes(int dim, int scap) {
+    return sizeof(double) * (static_cast<size_t>(dim) * scap + kNnScratch) + sizeof(float) * static_cast<size_t>(dim) * scap;
+}
+
+template <int D>
+__global__ void __launch_bounds__(kNnThreads)
+nn_tile_kernel(const double* __restrict__ q, int64_t n, const double* __restrict__ t, int64_t m, int split_len, int scap,
+               double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
+    extern __shared__ __attribute__((aligned(16))) double nn_tile_lds[];
+    const int tid = threadIdx.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
+    const int mt = static_cast<int>(m - t0 < split_len ? m - t0 : split_len);
+    const int m4 = (mt + 3) & ~3;
+    LdsView<D> L;
+    double* p = nn_tile_lds;
+    for (int d = 0; d < 3; d++) {
+        L.t[d] = d < D ? p : nullptr;
+        if (d < D) p += scap;
+    }
+    L.gs = p;
+    p += kNnScratch;
+    L.bc = nullptr;
+    L.skey = nullptr;
+    L.sval = nullptr;
+    float* f = reinterpret_cast<float*>(p);
+    for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
+    L.j0 = static_cast<int>(t0);
+    double qq[kNnTileQpt][D], best[kNnTileQpt];
+    int bidx[kNnTileQpt];
+    const int64_t qbase = static_cast<int64_t>(blockIdx.x) * (kNnThreads * kNnTileQpt);
+#pragma unroll
+    for (int k = 0; k < kNnTileQpt; k++) {
+        const int64_t i = qbase + tid + k * kNnThreads;
+#pragma unroll
+        for (int d = 0; d < D; d++) qq[k][d] = i < n ? q[i * D + d] : 0.0;
+    }
+    const FilterFrame F = stage_targets<D>(t + t0 * D, mt, m4, kNnThreads, L, true);
+    nn_twomin<D, kNnTileQpt>(qq, L, m4, F, best, bidx);
+#pragma unroll
+    for (int k = 0; k < kNnTileQpt; k++) {
+        const int64_t i = qbase + tid + k * kNnThreads;
+        if (i < n) {
+            // a split without any finite distance reports (inf, its first index), as nn_brute_kernel does
+            const bool none = !(best[k] < __builtin_inf());
+            part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = none ? __builtin_inf() : best[k];
+            part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = none ? static_cast<int>(t0) : bidx[k];
         }
     }
 }
