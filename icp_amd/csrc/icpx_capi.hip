@@ -743,7 +743,7 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
     }
 
     bool use_grid = mode == ICPX_NN_GRID ||
-                    (mode == ICPX_NN_AUTO && static_cast<double>(n) * static_cast<double>(m) > 64.0 * 1024 * 1024);
+                    (mode == ICPX_NN_AUTO && static_cast<double>(n) * static_cast<double>(m) > 512.0 * 1024 * 1024);  // measured crossover of one build + query: ~3e4 x 3e4
     if (m == 0) use_grid = false;
     if (use_grid) {
         if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));

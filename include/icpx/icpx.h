@@ -58,7 +58,7 @@ enum icpx_method {
 };
 
 enum icpx_nn_mode {
-    ICPX_NN_AUTO = 0,  /* brute force for small clouds, uniform grid for large ones */
+    ICPX_NN_AUTO = 0,  /* brute force (LDS tiles, f32 filter + exact f64) up to ~3e4 x 3e4, uniform grid beyond */
     ICPX_NN_BRUTE = 1, /* LDS-tiled brute force                                     */
     ICPX_NN_GRID = 2   /* exact uniform-grid search                                 */
 };
