@@ -110,7 +110,11 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
     PairGeom r;
     if (n <= 256) { r.qpt = 1; r.threads = 256; }
     else if (n <= 512) { r.qpt = 2; r.threads = 256; }
-    else if (n <= 1024) { r.qpt = 4; r.threads = 256; }  // measured: 16.1 vs 13.7 TFLOP/s for (2,512)
+    else if (n <= 1024) {
+        // batches: (4,256) has the higher throughput (several workgroups share a CU); a single pair
+        // owns its CU and iterates 1.4x faster with twice the threads (59 vs 85 us at n = m = 1024)
+        if (want_matches) { r.qpt = 2; r.threads = 512; } else { r.qpt = 4; r.threads = 256; }
+    }
     else if (n <= 2048) { if (dim == 2) { r.qpt = 8; r.threads = 256; } else { r.qpt = 4; r.threads = 512; } }
     else { r.qpt = 8; r.threads = 512; }
     // development override: ICPX_GEOM="qpt,threads" (must cover n)
@@ -189,6 +193,7 @@ int launch_dm(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream
         case 20256: return launch_one<D, METHOD, 2, 256>(pb, n_pairs, g, stream);
         case 40256: return launch_one<D, METHOD, 4, 256>(pb, n_pairs, g, stream);
         case 80256: return launch_one<D, METHOD, 8, 256>(pb, n_pairs, g, stream);
+        case 20512: return launch_one<D, METHOD, 2, 512>(pb, n_pairs, g, stream);
         case 40512: return launch_one<D, METHOD, 4, 512>(pb, n_pairs, g, stream);
         case 80512: return launch_one<D, METHOD, 8, 512>(pb, n_pairs, g, stream);
         default: return fail(ICPX_ERR_INVALID, "no fused kernel for %d queries per lane x %d threads", g.qpt, g.threads);
