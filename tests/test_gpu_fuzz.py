@@ -1,0 +1,20 @@
+"""Randomized differential test of the fused kernels against the oracle (tests/tools/fuzz_filter.py):
+random dimension, method, sizes, scales from 1e-6 to 1e6, offsets up to 1e5 x scale, lattices,
+duplicated targets, collinear targets, with and without the iteration-granular scheduler."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_fuzz_fused_kernels_against_oracle(seed):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_filter.py"), str(seed), "60"],
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "0 mismatches" in out.stdout

@@ -192,7 +192,7 @@ def test_reference_3d_cases_on_oracle(ob, modes):
 
 
 def test_golden_traces_reproduce(ob, scans, queen, traces):
-    """The committed traces (tools/make_golden.py) pin the oracle; SURVEY §8c sanity anchors too."""
+    """The committed traces (tests/tools/make_golden.py) pin the oracle; SURVEY §8c sanity anchors too."""
     for key, g in traces.items():
         data, method, mode = key.split("/")
         nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if mode == "ref" else (ob.NN_BRUTE, ob.SUM_TREE64)

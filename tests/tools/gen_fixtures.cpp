@@ -5,7 +5,7 @@
 //   * 2D noise: default-seeded std::default_random_engine, normal_distribution(0, 1), 4 x 2 draws
 //     in the order tests/test.cpp:197-210 consumes them
 //   * 3D noise: same engine, 3 x 3 draws in the order tests/test3d.cpp:178-195 consumes them
-// Build + run: g++ -O2 -o /tmp/gen_fixtures tools/gen_fixtures.cpp && /tmp/gen_fixtures tests/golden
+// Build + run: g++ -O2 -o /tmp/gen_fixtures tests/tools/gen_fixtures.cpp && /tmp/gen_fixtures tests/golden
 #include <cstdio>
 #include <random>
 #include <string>

@@ -1,6 +1,6 @@
 """Quick GPU sanity run (development aid): product vs oracle on the example data."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import icp_amd
 from icp_amd import io as iio

@@ -6,7 +6,7 @@ and its method classes cannot be built here (Eigen is absent), so these vectors 
 oracle restatement.  They pin the oracle against regressions and give the GPU tests a committed
 target; they are not outputs of the reference itself.
 
-Run:  python tools/make_golden.py
+Run:  python tests/tools/make_golden.py
 """
 import json
 import os
@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from icp_amd import io as iio  # noqa: E402
 from oracle import binding as ob  # noqa: E402
