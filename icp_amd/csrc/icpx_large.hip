@@ -178,7 +178,10 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
 // split), seedless otherwise.  Per-split results are merged by lg_tile_merge_kernel in the (d2, index)
 // order.  On 256 CUs this beats the grid walk up to about 3e4 x 3e4 points.
 constexpr int64_t kGridSortMinQueries = 32768;
-constexpr int kTileThreads = 256;
+#ifndef ICPX_TILE_THREADS
+#define ICPX_TILE_THREADS 256
+#endif
+constexpr int kTileThreads = ICPX_TILE_THREADS;
 #ifndef ICPX_TILE_QPT
 #define ICPX_TILE_QPT 4
 #endif

@@ -633,6 +633,9 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
     const int tid = threadIdx.x;
     const int P = pb.n_pairs;
     const int home = static_cast<int>(static_cast<long long>(blockIdx.x) * P / gridDim.x);
+#ifdef ICPX_STATS
+    const uint64_t stat_alive0 = wall_clock64();
+#endif
     for (int guard = 0; guard < (1 << 30); guard++) {
         if (tid == 0) s_key = 0x7fffffff;
         __syncthreads();
@@ -676,7 +679,16 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
         if (pick == -1) break;
         if (pick == -2) continue;
         const int q = pick >> 1;
+#ifdef ICPX_STATS
+        const uint64_t stat_t0 = wall_clock64();
+#endif
         const int code = pair_body<D, METHOD, QPT>(pb, q, pick & 1, static_cast<uint64_t>(pb.sched_steps), lds_raw);
+#ifdef ICPX_STATS
+        if (tid == 0) {
+            atomicAdd(&g_icpx_stats[5], static_cast<unsigned long long>(wall_clock64() - stat_t0));  // busy ticks
+            atomicAdd(&g_icpx_stats[6], 1ULL);                                                         // tasks
+        }
+#endif
         // pair_body ended with a barrier behind every wave's stores
         if (tid == 0) {
             const int iters = static_cast<int>(pb.states[q].iteration_count);
@@ -687,6 +699,9 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
             if (code == 1) atomicAdd(pb.sched_done, 1);
         }
     }
+#ifdef ICPX_STATS
+    if (tid == 0) atomicAdd(&g_icpx_stats[7], static_cast<unsigned long long>(wall_clock64() - stat_alive0));  // alive ticks
+#endif
 }
 
 }  // namespace icpx
