@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
     // release / acquire recipe: every wave drains its stores and meets at the barrier (end of
     // pair_body), lane 0 releases, then publishes the state word; the taker wins the word with a
     // CAS, acquires, and only then lets the workgroup load.
-    __shared__ int s_key, s_pick;
+    __shared__ int s_key, s_pick, s_ready;
     const int tid = threadIdx.x;
     const int P = pb.n_pairs;
     const int home = static_cast<int>(static_cast<long long>(blockIdx.x) * P / gridDim.x);
@@ -637,9 +637,13 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
     const uint64_t stat_alive0 = wall_clock64();
 #endif
     for (int guard = 0; guard < (1 << 30); guard++) {
-        if (tid == 0) s_key = 0x7fffffff;
+        if (tid == 0) {
+            s_key = 0x7fffffff;
+            s_ready = 0;
+        }
         __syncthreads();
         int best = 0x7fffffff;
+        int ready = 0;
         for (int q = tid; q < P; q += blockDim.x) {
             int w = __hip_atomic_load(&pb.sched_state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int st = w & 3;
@@ -652,9 +656,13 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
                 rot += rot < 0 ? P : 0;
                 int key = ((it < 2047 ? it : 2047) << 20) | rot;
                 best = key < best ? key : best;
+                ready++;
             }
         }
-        if (best != 0x7fffffff) atomicMin(&s_key, best);
+        if (best != 0x7fffffff) {
+            atomicMin(&s_key, best);
+            atomicAdd(&s_ready, ready);
+        }
         __syncthreads();
         if (tid == 0) {
             int pick = -2;  // retry
@@ -679,10 +687,14 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
         if (pick == -1) break;
         if (pick == -2) continue;
         const int q = pick >> 1;
+        // while at least half as many pairs are waiting as there are workgroups, a task carries two iterations
+        // (half the hand-offs and restagings); in the tail it carries one, for balance
+        const uint64_t task_steps =
+            static_cast<uint64_t>(pb.sched_steps) * (2 * s_ready > static_cast<int>(gridDim.x) ? 2 : 1);
 #ifdef ICPX_STATS
         const uint64_t stat_t0 = wall_clock64();
 #endif
-        const int code = pair_body<D, METHOD, QPT>(pb, q, pick & 1, static_cast<uint64_t>(pb.sched_steps), lds_raw);
+        const int code = pair_body<D, METHOD, QPT>(pb, q, pick & 1, task_steps, lds_raw);
 #ifdef ICPX_STATS
         if (tid == 0) {
             atomicAdd(&g_icpx_stats[5], static_cast<unsigned long long>(wall_clock64() - stat_t0));  // busy ticks
