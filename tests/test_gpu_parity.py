@@ -511,6 +511,46 @@ def test_corrected_modes_match_oracle(icp, ob, scans):
             assert r.cost == ro.cost
 
 
+def test_handles_from_several_threads_and_reuse(icp, ob, scans, queen):
+    """Different handles used concurrently from several host threads (the reference's instances are
+    independent objects too), each re-used for clouds of different sizes: every result equals the
+    single-threaded one; the handle-free entry points serialise on the per-device workspace."""
+    import threading
+    from icp_amd import synth
+    s3, t3, off3, _ = synth.config5_pairs(np.arange(6), 3, 900)
+    jobs = [(icp.ICP2, "trimmed", *scans[1], BENCH_CRIT), (icp.ICP2, "vanilla", *scans[2], BENCH_CRIT),
+            (icp.ICP3, "vanilla", *queen, PLY_CRIT), (icp.ICP2, "feature_aware", *scans[3], BENCH_CRIT),
+            (icp.ICP3, "trimmed", s3[:900], t3[:900], dict(max_iterations=10))]
+    expect = [driver(icp, c, m, crit).converge(a, b) for c, m, a, b, crit in jobs]
+    exp_batch = icp.converge_batch(3, "vanilla", s3, off3, t3, off3, icp.make_criteria(max_iterations=5), device=0)
+    errors = []
+
+    def worker(w):
+        try:
+            d = {}
+            for rep in range(6):
+                k = (w + rep) % len(jobs)
+                c, m, a, b, crit = jobs[k]
+                if (c, m) not in d:
+                    d[(c, m)] = driver(icp, c, m, crit)
+                r = d[(c, m)].converge(a, b)
+                if not (np.array_equal(r.transform, expect[k].transform) and r.iteration_count == expect[k].iteration_count
+                        and r.cost == expect[k].cost):
+                    errors.append(("handle", w, rep, k))
+                got = icp.converge_batch(3, "vanilla", s3, off3, t3, off3, icp.make_criteria(max_iterations=5), device=0)
+                if not all(np.array_equal(u, v) for u, v in zip(got, exp_batch)):
+                    errors.append(("batch", w, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", w, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_driver_criteria_on_device(icp, ob, scans):
     a, b = scans[1]
     for crit in [dict(max_iterations=5), dict(max_iterations=0), dict(min_iterations=7, max_iterations=50, stop_cost=1e9),
