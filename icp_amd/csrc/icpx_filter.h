@@ -159,6 +159,17 @@ ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, do
     }
 }
 
+ICPX_DEV float raw_min_f32(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+ICPX_DEV float raw_max_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // per-lane filter operands of the QPT queries; returns false when this lane cannot use the filter
 template <int D, int QPT>
 ICPX_DEV bool filter_queries(const double (&q)[QPT][D], const FilterFrame& F, float (&q2)[QPT][D], float (&qn)[QPT],
@@ -460,8 +471,10 @@ ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m4, 
         for (int k = 0; k < QPT; k++) {
             float mn = block_filter_min<D>(tc, tn, q2[k]);
             bool lt = mn < b1[k];
-            b2[k] = __builtin_fminf(b2[k], __builtin_fmaxf(b1[k], mn));
-            b1[k] = __builtin_fminf(b1[k], mn);
+            // plain v_max / v_min: the values are never NaN here, and the builtins would re-quiet the
+            // loop-carried operands on every step (two extra instructions per slot and block)
+            b2[k] = raw_min_f32(b2[k], raw_max_f32(b1[k], mn));
+            b1[k] = raw_min_f32(b1[k], mn);
             blk[k] = lt ? jb : blk[k];
         }
     }
