@@ -696,9 +696,9 @@ int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double
 // development builds only (-DICPX_STATS): read / reset the kernel statistics counters
 int icpx_debug_stats(unsigned long long* out, int reset) {
     ICPX_HIP(hipDeviceSynchronize());
-    if (out) ICPX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(icpx::g_icpx_stats), sizeof(unsigned long long) * 8));
+    if (out) ICPX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(icpx::g_icpx_stats), sizeof(unsigned long long) * 16));
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         ICPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_icpx_stats), z, sizeof(z)));
     }
     return ICPX_OK;

@@ -93,7 +93,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // development statistics (build with -DICPX_STATS; read with icpx_debug_stats):
 //   0 seeded scans (wave)  1 exact flushes (wave)  2 two-min scans (wave)  3 near-tie lanes  4 slot rescans (wave)
 #ifdef ICPX_STATS
-__device__ unsigned long long g_icpx_stats[8];
+__device__ unsigned long long g_icpx_stats[16];
 #define ICPX_STAT(slot_, amount_)                                                                    \
     do {                                                                                             \
         unsigned long long stat_v_ = (unsigned long long)(amount_);                                  \

@@ -409,6 +409,18 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 
         if (!empty) {
             // ================= iterate() =================
+#ifdef ICPX_STATS
+            uint64_t ph0 = wall_clock64();
+#define ICPX_PHASE(slot_)                                                                              \
+    do {                                                                                               \
+        __syncthreads(); /* stats builds only: phases end when the slowest wave gets there */         \
+        uint64_t ph1 = wall_clock64();                                                                 \
+        if (tid == 0) atomicAdd(&g_icpx_stats[slot_], static_cast<unsigned long long>(ph1 - ph0));     \
+        ph0 = ph1;                                                                                     \
+    } while (0)
+#else
+#define ICPX_PHASE(slot_) do { } while (0)
+#endif
             double cur[QPT][D];
             int sel[QPT];
             int k_sel = n;
@@ -439,7 +451,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                     for (int k = 0; k < QPT; k++) skeys[k] = static_cast<uint64_t>(__double_as_longlong(cost[k]));
                     uint64_t kth;
                     uint32_t vth;
+                    ICPX_PHASE(8);   // correspondence search
                     radix_select<QPT>(skeys, valid, T, k_sel, reinterpret_cast<int*>(L.gs), kth, vth);
+                    ICPX_PHASE(9);   // selection
 #pragma unroll
                     for (int k = 0; k < QPT; k++) {
                         uint64_t kk = static_cast<uint64_t>(__double_as_longlong(cost[k]));
@@ -471,6 +485,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 if (METHOD == ICPX_TRIMMED) k_sel = block_count<QPT>(sel, T, L.gs);
             }
 
+            if (!(D == 2 && METHOD == ICPX_TRIMMED)) ICPX_PHASE(8);
             // matched target coordinates
             double bp[QPT][D];
 #pragma unroll
@@ -511,6 +526,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 },
                 n, T, L.gs, s2);
 
+            ICPX_PHASE(10);  // sums
             if (tid == 0) {
                 Mat<D> N;
 #pragma unroll
@@ -537,6 +553,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             }
             if (D == 2 && METHOD == ICPX_TRIMMED) state_cost = __builtin_sqrt(s1[2 * D] / static_cast<double>(n));
             __syncthreads();
+            ICPX_PHASE(11);  // Kabsch + broadcast
         }
         if (tid == 0) {
             st->iteration_count += 1;

@@ -1,0 +1,19 @@
+"""Development aid (needs a -DICPX_STATS build): time per phase of the fused iteration (thread 0 of every
+workgroup, 100 MHz wall clock).  usage: phase_stats.py dim n pairs iters method"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import icp_amd
+from icp_amd import synth
+dim, n, pairs, iters, method = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+lib = icp_amd._lib.load()
+s, t, off, _ = synth.config5_pairs(np.arange(pairs), dim, n)
+crit = icp_amd.make_criteria(min_iterations=iters, max_iterations=iters)
+out = (C.c_ulonglong * 16)()
+icp_amd.converge_batch(dim, method, s, off, t, off, crit, device=0)
+lib.icpx_debug_stats(out, 1)
+icp_amd.converge_batch(dim, method, s, off, t, off, crit, device=0)
+lib.icpx_debug_stats(out, 0)
+tot = pairs * iters
+for nm, i in (("search", 8), ("selection", 9), ("sums", 10), ("kabsch+broadcast", 11)):
+    print(f"{nm:18s} {out[i] / tot / 100:8.2f} us per pair-iteration")
