@@ -130,6 +130,7 @@ def main():
         k3 = float(np.mean(k3_ms)) if k3_ms else float("nan")
         flops3 = float((it3 * (8.0 * N_3D * N_3D)).sum())
         achieved = flops3 / (k3 * 1e-3) / 1e12
+        traffic = measured_traffic()
         line = {
             "metric": "nn_correspondence_queries_per_s",
             "value": total_q / (elapsed / args.steps),
@@ -168,7 +169,10 @@ def main():
                 "frac_of_unfused_peak": achieved / (FP64_PEAK_TFLOPS / 2),
                 "launch_ms": k3,
                 "flops_per_launch": flops3,
-                "traffic": measured_traffic(),
+                "traffic": traffic,
+                # the other roofline of the same launch: HBM bytes (PMC, profiles/) over its duration
+                "hbm": None if traffic is None else {"achieved": traffic / (k3 * 1e-3) / 1e9, "peak": 8000.0,
+                                                     "unit": "GB/s", "frac": traffic / (k3 * 1e-3) / 1e9 / 8000.0},
             },
         }
         if not args.no_extras and world == 1:
