@@ -221,6 +221,9 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
         r = drv.converge(a, b)
     ex["c2_scan1_trimmed_converge_ms"] = (time.perf_counter() - t0) / 20 * 1e3
     ex["c2_scan1_iterations"] = r.iteration_count
+    # M1 / M2 of SURVEY 8(d) for this config: trimmed ICP2 matches once in setup and once per iterate
+    ex["c2_scan1_queries_per_s"] = (r.iteration_count + 1) * len(a) / (ex["c2_scan1_trimmed_converge_ms"] * 1e-3)
+    ex["c2_scan1_pairs_per_s"] = 1e3 / ex["c2_scan1_trimmed_converge_ms"]
     # config 3: queen.ply, vanilla ICP3
     q = iio.read_ply_vertices(os.path.join(g, "ply", "queen.ply"))
     qt = iio.read_ply_vertices(os.path.join(g, "ply", "queen_transformed.ply"))
@@ -233,6 +236,8 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
         r = drv3.converge(qt, q)
     ex["c3_queen_vanilla3d_converge_ms"] = (time.perf_counter() - t0) / 10 * 1e3
     ex["c3_queen_iterations"] = r.iteration_count
+    ex["c3_queen_queries_per_s"] = r.iteration_count * len(qt) / (ex["c3_queen_vanilla3d_converge_ms"] * 1e-3)
+    ex["c3_queen_pairs_per_s"] = 1e3 / ex["c3_queen_vanilla3d_converge_ms"]
     # config 4: 1M x 1M grid NN, one correspondence step, inputs and outputs resident in HBM
     src, tgt, _, _ = synth.config4(1_000_000)
     d_q, d_t = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
