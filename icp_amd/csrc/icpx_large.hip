@@ -35,6 +35,10 @@ constexpr int kBlk = 1024;          // threads per reduction block
 constexpr int kSlots = 4;           // points per thread -> 4096 points (64 TREE64 groups) per block
 constexpr int kBlkPts = kBlk * kSlots;
 constexpr int64_t kLargeMaxN = int64_t(1) << 24;  // <= 4096 block partials -> at most 4 tree levels
+// up to here (<= 4096 TREE64 groups) the sum kernels write level-1 group sums from many small blocks
+// and the finishing block walks the remaining levels: a few thousand points cannot fill 4096-point blocks
+constexpr int64_t kGroupSumMaxN = int64_t(1) << 18;
+constexpr int kGroupBlk = 256;      // threads per block in that mode: one group per wave
 
 struct GridIndex {
     GridParams gp{};
@@ -67,7 +71,8 @@ struct LargeIcp {
     double clock_to_s = 1e-8;
     hipStream_t stream = nullptr;
     int64_t n = 0, m = 0;
-    int nblk = 0;
+    int nblk = 0;         // partials per summed term: 4096-point blocks, or 64-point groups when `groups`
+    bool groups = false;  // n <= kGroupSumMaxN
     GridIndex* grid = nullptr;
     DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
     // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
@@ -404,7 +409,28 @@ ICPX_DEV void block_tree(F&& f, int64_t n, double* __restrict__ part, int nblk, 
     }
 }
 
-// remaining TREE64 levels over the per-block partials; every thread gets the total.
+// TREE64 level 1 only: one 64-point group per wave, part[v * G1 + group]
+template <int NV, typename F>
+ICPX_DEV void group_tree(F&& f, int64_t n, double* __restrict__ part, int G1) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= G1) return;
+    const int64_t i = static_cast<int64_t>(g) * 64 + lane;
+    double vals[NV];
+    if (i < n) {
+        f(i, vals);
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; v++) vals[v] = 0.0;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        double s = wave_sum(vals[v]);
+        if (lane == 0) part[static_cast<int64_t>(v) * G1 + g] = s;
+    }
+}
+
+// remaining TREE64 levels over the per-block (or per-group) partials; every thread gets the total.
 ICPX_DEV double fin_tree(const double* __restrict__ part, int nblk, double* lds) {
     if (nblk == 1) return part[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
@@ -606,7 +632,7 @@ __global__ void __launch_bounds__(kBlk)
 lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
                const double* __restrict__ nb_cost, const uint8_t* __restrict__ sel, double* __restrict__ part,
-               int* __restrict__ cntp, int nblk) {
+               int* __restrict__ cntp, int nblk, int groups) {
     __shared__ double gs[(2 * D + 1) * 64];
     __shared__ int wcnt[kBlk / 64];
     if (respect_done && dev->st.done) return;
@@ -615,14 +641,7 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
     for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
     XfRows<D> xr = xf_rows<D>(X);
     const bool with_cost = dev->with_cost != 0;
-    int cnt = 0;
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
-    for (int k = 0; k < kSlots; k++) {
-        int64_t i = base + k * kBlk + threadIdx.x;
-        if (i < n) cnt += sel[i];
-    }
-    block_tree<2 * D + 1>(
-        [&](int64_t i, double (&v)[2 * D + 1]) {
+    auto terms = [&](int64_t i, double (&v)[2 * D + 1]) {
             double p[D], c[D];
             if (D == 2) {
 #pragma unroll
@@ -640,8 +659,23 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
                 v[D + d] = s ? dst[j * D + d] : 0.0;
             }
             v[2 * D] = with_cost ? nb_cost[i] : 0.0;
-        },
-        n, part, nblk, gs);
+        };
+    if (groups) {
+        const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (g >= nblk) return;
+        const int64_t i = static_cast<int64_t>(g) * 64 + (threadIdx.x & 63);
+        int c = wave_sum_int(i < n ? sel[i] : 0);
+        if ((threadIdx.x & 63) == 0) cntp[g] = c;
+        group_tree<2 * D + 1>(terms, n, part, nblk);
+        return;
+    }
+    int cnt = 0;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
+    for (int k = 0; k < kSlots; k++) {
+        int64_t i = base + k * kBlk + threadIdx.x;
+        if (i < n) cnt += sel[i];
+    }
+    block_tree<2 * D + 1>(terms, n, part, nblk, gs);
     cnt = wave_sum_int(cnt);
     if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = cnt;
     __syncthreads();
@@ -657,12 +691,18 @@ __global__ void __launch_bounds__(kBlk)
 lg_fin1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, const int* __restrict__ cntp,
                int nblk) {
     __shared__ double lds[64];
+    __shared__ int wcnt[kBlk / 64];
     if (respect_done && dev->st.done) return;
     double s[2 * D + 1];
     for (int v = 0; v < 2 * D + 1; v++) s[v] = fin_tree(part + static_cast<int64_t>(v) * nblk, nblk, lds);
+    int c = 0;  // <= 2^24 selected points in all
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) c += cntp[b];
+    c = wave_sum_int(c);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
+    __syncthreads();
     if (threadIdx.x == 0) {
         long long k = 0;
-        for (int b = 0; b < nblk; b++) k += cntp[b];
+        for (int w = 0; w < static_cast<int>(blockDim.x >> 6); w++) k += wcnt[w];
         double kd = static_cast<double>(k);
         for (int d = 0; d < D; d++) {
             dev->ca[d] = s[d] / kd;
@@ -677,7 +717,7 @@ template <int D, int METHOD>
 __global__ void __launch_bounds__(kBlk)
 lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
-               const uint8_t* __restrict__ sel, double* __restrict__ part, int nblk) {
+               const uint8_t* __restrict__ sel, double* __restrict__ part, int nblk, int groups) {
     __shared__ double gs[D * D * 64];
     if (respect_done && dev->st.done) return;
     Xf<D> X;
@@ -690,8 +730,7 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
         ca[d] = dev->ca[d];
         cb[d] = dev->cb[d];
     }
-    block_tree<D * D>(
-        [&](int64_t i, double (&v)[D * D]) {
+    auto terms = [&](int64_t i, double (&v)[D * D]) {
             double p[D], c[D], b[D];
             if (D == 2) {
 #pragma unroll
@@ -709,8 +748,11 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
             for (int r = 0; r < D; r++)
 #pragma unroll
                 for (int cc = 0; cc < D; cc++) v[cc * D + r] = s ? (c[r] - ca[r]) * (b[cc] - cb[cc]) : 0.0;
-        },
-        n, part, nblk, gs);
+        };
+    if (groups)
+        group_tree<D * D>(terms, n, part, nblk);
+    else
+        block_tree<D * D>(terms, n, part, nblk, gs);
 }
 
 // setup tail: ICP::calculate_cost of the initial matches, then the loop's first should_terminate
@@ -1064,20 +1106,21 @@ namespace {
 template <int D, int METHOD>
 int enqueue_sums(LargeIcp* lg, int respect_done, bool second) {
     LargeDev* dev = lg->dev.as<LargeDev>();
-    const int nblk = lg->nblk;
+    const int nblk = lg->nblk, groups = lg->groups ? 1 : 0;
+    const dim3 grid(groups ? (nblk + kGroupBlk / 64 - 1) / (kGroupBlk / 64) : nblk), block(groups ? kGroupBlk : kBlk);
     if (!second) {
-        hipLaunchKernelGGL((lg_sum1_kernel<D, METHOD>), dim3(nblk), dim3(kBlk), 0, lg->stream, dev, respect_done,
+        hipLaunchKernelGGL((lg_sum1_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->n,
                            lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(),
-                           lg->part.as<double>(), lg->cntp.as<int>(), nblk);
+                           lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups);
         ICPX_HIP(hipGetLastError());
         hipLaunchKernelGGL(lg_fin1_kernel<D>, dim3(1), dim3(kBlk), 0, lg->stream, dev, respect_done,
                            lg->part.as<double>(), lg->cntp.as<int>(), nblk);
         ICPX_HIP(hipGetLastError());
     } else {
-        hipLaunchKernelGGL((lg_sum2_kernel<D, METHOD>), dim3(nblk), dim3(kBlk), 0, lg->stream, dev, respect_done,
+        hipLaunchKernelGGL((lg_sum2_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->n,
-                           lg->nb_idx.as<int64_t>(), lg->sel.as<uint8_t>(), lg->part.as<double>(), nblk);
+                           lg->nb_idx.as<int64_t>(), lg->sel.as<uint8_t>(), lg->part.as<double>(), nblk, groups);
         ICPX_HIP(hipGetLastError());
     }
     return ICPX_OK;
@@ -1268,7 +1311,8 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     if (n > kLargeMaxN) return fail(ICPX_ERR_UNSUPPORTED, "source cloud above %lld points", (long long)kLargeMaxN);
     lg->n = n;
     lg->m = m;
-    lg->nblk = static_cast<int>((n + kBlkPts - 1) / kBlkPts);
+    lg->groups = n <= kGroupSumMaxN && !getenv("ICPX_NO_GROUP_SUMS");
+    lg->nblk = static_cast<int>(lg->groups ? (n + 63) / 64 : (n + kBlkPts - 1) / kBlkPts);
     ICPX_TRY(lg->src.reserve(sizeof(double) * D * n));
     ICPX_TRY(lg->dst.reserve(sizeof(double) * D * m));
     ICPX_TRY(lg->cur.reserve(sizeof(double) * D * n));

@@ -342,6 +342,41 @@ def test_large_path_sizes_and_engines(icp, ob, nn):
         assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
 
 
+def test_large_path_sum_layouts_agree(icp, ob, monkeypatch):
+    """The multi-kernel path sums per 64-point group (n <= 2^18) or per 4096-point block (beyond, or
+    ICPX_NO_GROUP_SUMS): both walk the same TREE64 tree, so a converge must not change by one bit;
+    sizes around the group / block boundaries, and one cloud beyond 2^18 against the oracle."""
+    from icp_amd import synth
+    crit = dict(max_iterations=5, transform_tol=(1e-9, 1e-9))
+    for dim, method, n, m in ((3, "vanilla", 4160, 5000), (3, "trimmed", 8193, 4500), (2, "trimmed", 12289, 6000),
+                              (2, "vanilla", 4097, 4097), (3, "vanilla", 65, 9000), (3, "vanilla", 64, 9000)):
+        s, t, _, _ = synth.config5_pairs([n + m], dim, max(n, m))
+        s, t = s[:n], t[:m]
+        cfg = icp.Config()
+        cfg.set("nn", "grid")  # the multi-kernel path at any size
+        cfg.set("max_distance", 0.35)
+        cls = icp.ICP2 if dim == 2 else icp.ICP3
+        out = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("ICPX_NO_GROUP_SUMS", env)
+            d = driver(icp, cls, method, crit, cfg)
+            r = d.converge(s, t)
+            out.append((r.iteration_count, r.transform.copy(), r.cost))
+            monkeypatch.delenv("ICPX_NO_GROUP_SUMS", raising=False)
+        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2], (dim, method, n)
+        ro = dev_oracle(ob, dim, method, max_distance=0.35).converge(s, t, None, ob.make_criteria(**crit))
+        assert out[0][0] == ro.iteration_count and np.array_equal(out[0][1], ro.transform) and out[0][2] == ro.cost
+    # beyond 2^18 source points: block sums only; few targets keep the oracle's brute force short
+    n, m = (1 << 18) + 77, 700
+    s, t, _, _ = synth.config5_pairs([n + m], 3, n)
+    s, t = s[:n], t[:m]
+    crit = dict(max_iterations=2)
+    r = driver(icp, icp.ICP3, "vanilla", crit).converge(s, t)
+    ro = dev_oracle(ob, 3, "vanilla").converge(s, t, None, ob.make_criteria(**crit))
+    assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
+
+
 def test_filtered_search_adversarial_inputs(icp, ob):
     """The f32 candidate filter of the fused kernel must never change a result: exact ties
     (lattices, duplicated targets), clouds far from the origin (the filter works about the target's
