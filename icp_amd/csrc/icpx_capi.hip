@@ -28,6 +28,18 @@
 
 namespace icpx {
 
+// the fused kernels live in four objects built from icpx_pair_inst.hip
+int launch_pairs_d2_plain(const PairBatch&, int64_t, const PairLaunch&, hipStream_t);
+int launch_pairs_d2_prune(const PairBatch&, int64_t, const PairLaunch&, hipStream_t);
+int launch_pairs_d3_plain(const PairBatch&, int64_t, const PairLaunch&, hipStream_t);
+int launch_pairs_d3_prune(const PairBatch&, int64_t, const PairLaunch&, hipStream_t);
+#ifdef ICPX_STATS
+int stats_read_d2_plain(unsigned long long*, int);
+int stats_read_d2_prune(unsigned long long*, int);
+int stats_read_d3_plain(unsigned long long*, int);
+int stats_read_d3_prune(unsigned long long*, int);
+#endif
+
 std::string& last_error_ref() {
     static thread_local std::string s;
     return s;
@@ -35,7 +47,7 @@ std::string& last_error_ref() {
 
 namespace {
 
-constexpr size_t kMaxLds = 160 * 1024 - 256;  // dynamic LDS budget (the kernel keeps a few static words)
+constexpr size_t kMaxLds = kPairMaxLds;
 
 struct DeviceInfo {
     bool ok = false;
@@ -101,11 +113,13 @@ constexpr double kFusedSingleMaxWork = 1.1e6;  // measured crossover (n = m = 10
 struct PairGeom {
     int qpt, threads, tcap, scap;
     bool filter;  // f32 target copy reserved in LDS (nn_filtered)
+    bool prune;   // Morton-ordered clouds + target boxes (icpx_prune.h); batches only
     size_t lds;
 };
 
 // does a pair of this size fit the fused kernel?
-bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool want_matches = true) {
+bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool want_matches = true,
+                bool allow_prune = false) {
     if (n > kPairMaxN || m > (1 << 20)) return false;
     PairGeom r;
     if (n <= 256) { r.qpt = 1; r.threads = 256; }
@@ -134,70 +148,20 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
     const char* fe = std::getenv("ICPX_FILTER");
     r.filter = !(dim == 2 && method == ICPX_VANILLA) && !(fe && fe[0] == '0') &&
                pair_lds_bytes(dim, r.tcap, r.scap, true) <= kMaxLds;
-    r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter);
+    r.prune = false;
+    if (allow_prune && r.filter && m >= 128 && m < 65536) {
+        // development override: ICPX_PRUNE=0
+        const char* pe = std::getenv("ICPX_PRUNE");
+        const int tcap16 = (r.tcap + kPruneBlk - 1) & ~(kPruneBlk - 1);
+        if (!(pe && pe[0] == '0') && pair_lds_bytes(dim, tcap16, r.scap, true, true) <= kMaxLds) {
+            r.prune = true;
+            r.tcap = tcap16;
+        }
+    }
+    r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter, r.prune);
     if (r.lds > kMaxLds) return false;
     if (g) *g = r;
     return true;
-}
-
-template <int D, int METHOD, int QPT, int TMAX>
-int launch_one(const PairBatch& pb_in, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
-    auto kern = pair_kernel<D, METHOD, QPT, TMAX>;
-    static std::mutex mu;
-    static std::unordered_map<int, bool> attr_set;  // per device
-    int dev = 0;
-    ICPX_HIP(hipGetDevice(&dev));
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!attr_set[dev]) {
-            ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(kMaxLds)));
-            attr_set[dev] = true;
-        }
-    }
-    PairBatch pb = pb_in;
-    int64_t blocks = n_pairs;
-    if (pb.sched_state) {
-        // iteration-granular scheduling pays when the pairs outnumber the resident workgroups only
-        // by a small factor (the tail of a pair-per-workgroup launch is then a large share)
-        DeviceInfo* di = nullptr;
-        ICPX_TRY(device_info(dev, &di));
-        int per_cu = 0;
-        ICPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, g.threads, g.lds));
-        const int64_t resident = static_cast<int64_t>(per_cu > 0 ? per_cu : 1) * di->cus;
-        const char* force = std::getenv("ICPX_SCHED");  // development override: 0 = never, 1 = always
-        bool use = n_pairs > resident && n_pairs <= 16 * resident && n_pairs < (1 << 20) &&
-                   !(D == 2 && METHOD == ICPX_VANILLA);
-        if (force) use = force[0] == '1' && n_pairs < (1 << 20) && !(D == 2 && METHOD == ICPX_VANILLA);
-        if (use) {
-            blocks = n_pairs < resident ? n_pairs : resident;
-            pb.n_pairs = static_cast<int32_t>(n_pairs);
-            pb.sched_steps = 1;
-            ICPX_HIP(hipMemsetAsync(pb.sched_state, 0, sizeof(int32_t) * (n_pairs + 1), stream));
-            pb.sched_done = pb.sched_state + n_pairs;
-        } else {
-            pb.sched_state = nullptr;
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(g.threads), g.lds, stream, pb);
-    ICPX_HIP(hipGetLastError());
-    return ICPX_OK;
-}
-
-template <int D, int METHOD>
-int launch_dm(const PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
-    const int key = g.qpt * 10000 + g.threads;
-    switch (key) {
-        case 10256: return launch_one<D, METHOD, 1, 256>(pb, n_pairs, g, stream);
-        case 20256: return launch_one<D, METHOD, 2, 256>(pb, n_pairs, g, stream);
-        case 40256: return launch_one<D, METHOD, 4, 256>(pb, n_pairs, g, stream);
-        case 80256: return launch_one<D, METHOD, 8, 256>(pb, n_pairs, g, stream);
-        case 20512: return launch_one<D, METHOD, 2, 512>(pb, n_pairs, g, stream);
-        case 40512: return launch_one<D, METHOD, 4, 512>(pb, n_pairs, g, stream);
-        case 80512: return launch_one<D, METHOD, 8, 512>(pb, n_pairs, g, stream);
-        default: return fail(ICPX_ERR_INVALID, "no fused kernel for %d queries per lane x %d threads", g.qpt, g.threads);
-    }
 }
 
 int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t stream) {
@@ -205,12 +169,19 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     pb.lds_target_cap = g.tcap;
     pb.lds_sort_cap = g.scap;
     pb.use_filter = g.filter ? 1 : 0;
-    if (pb.dim == 2) {
-        if (pb.method == ICPX_VANILLA) return launch_dm<2, ICPX_VANILLA>(pb, n_pairs, g, stream);
-        return launch_dm<2, ICPX_TRIMMED>(pb, n_pairs, g, stream);
-    }
-    if (pb.method == ICPX_VANILLA) return launch_dm<3, ICPX_VANILLA>(pb, n_pairs, g, stream);
-    return launch_dm<3, ICPX_TRIMMED>(pb, n_pairs, g, stream);
+    int dev = 0;
+    ICPX_HIP(hipGetDevice(&dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    PairLaunch pl;
+    pl.qpt = g.qpt;
+    pl.threads = g.threads;
+    pl.lds = g.lds;
+    pl.cus = di->cus;
+    const bool prune = g.prune && pb.sperm && pb.tperm && pb.xbest && pb.seeds;
+    if (g.prune && !prune) return fail(ICPX_ERR_INVALID, "pruned launch without its permutation buffers");
+    if (pb.dim == 2) return prune ? launch_pairs_d2_prune(pb, n_pairs, pl, stream) : launch_pairs_d2_plain(pb, n_pairs, pl, stream);
+    return prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream);
 }
 
 icpx_criteria no_criteria() {
@@ -223,6 +194,7 @@ icpx_criteria no_criteria() {
 struct Workspace {
     std::mutex mu;
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
+    DevBuf sperm, tperm, xbest;  // pruned search of the batch entry point
     GridIndex* grid = nullptr;  // grow-only uniform-grid index of the stand-alone queries
 };
 Workspace& workspace(int device) {
@@ -594,7 +566,7 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
     const int64_t n_total = source_offsets[n_pairs], m_total = target_offsets[n_pairs];
     if ((n_total > 0 && !source) || (m_total > 0 && !target)) return fail(ICPX_ERR_INVALID, "null source/target");
     PairGeom geom;
-    if (!fused_fits(dim, method, n_max, m_max, &geom, false))
+    if (!fused_fits(dim, method, n_max, m_max, &geom, false, true))
         return fail(ICPX_ERR_UNSUPPORTED,
                     "icpx_converge_batch: largest pair (%lld x %lld points) exceeds the fused kernel's limits; "
                     "run such pairs through icpx_converge", (long long)n_max, (long long)m_max);
@@ -663,6 +635,33 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
         ICPX_TRY(ws.seeds.reserve(sizeof(int32_t) * (n_total > 0 ? n_total : 1)));
         pb.seeds = ws.seeds.as<int32_t>();
     }
+    if (geom.prune) {
+        // Morton orders of all clouds (one pre-pass launch), exchange buffer of the search lanes
+        ICPX_TRY(ws.sperm.reserve(sizeof(uint16_t) * (n_total > 0 ? n_total : 1)));
+        ICPX_TRY(ws.tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
+        ICPX_TRY(ws.xbest.reserve(sizeof(double) * (n_total > 0 ? n_total : 1)));
+        const int npad = next_pow2(static_cast<int>(n_max > m_max ? n_max : m_max));
+        const size_t perm_lds = static_cast<size_t>(npad) * 12 + 512;
+        if (perm_lds > kMaxLds) return fail(ICPX_ERR_UNSUPPORTED, "permutation pre-pass: cloud too large");
+        auto pk = dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
+        {
+            static std::mutex mu;
+            static std::unordered_map<int, bool> attr_set;  // per device and dimension
+            std::lock_guard<std::mutex> lk2(mu);
+            if (!attr_set[dev * 4 + dim]) {
+                ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(kMaxLds)));
+                attr_set[dev * 4 + dim] = true;
+            }
+        }
+        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs), 2), dim3(npad >= 2048 ? 512 : 256), perm_lds, stream,
+                           d_src, ws.soff.as<int64_t>(), d_dst, ws.doff.as<int64_t>(), ws.sperm.as<uint16_t>(),
+                           ws.tperm.as<uint16_t>(), npad);
+        ICPX_HIP(hipGetLastError());
+        pb.sperm = ws.sperm.as<uint16_t>();
+        pb.tperm = ws.tperm.as<uint16_t>();
+        pb.xbest = ws.xbest.as<double>();
+    }
     pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ICPX_TRY(launch_pairs(pb, n_pairs, geom, stream));
     if (!out_on_device) {
@@ -696,11 +695,12 @@ int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double
 // development builds only (-DICPX_STATS): read / reset the kernel statistics counters
 int icpx_debug_stats(unsigned long long* out, int reset) {
     ICPX_HIP(hipDeviceSynchronize());
-    if (out) ICPX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(icpx::g_icpx_stats), sizeof(unsigned long long) * 16));
-    if (reset) {
-        unsigned long long z[16] = {0};
-        ICPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_icpx_stats), z, sizeof(z)));
-    }
+    unsigned long long acc[16] = {0};
+    ICPX_TRY(stats_read_d2_plain(acc, reset));
+    ICPX_TRY(stats_read_d2_prune(acc, reset));
+    ICPX_TRY(stats_read_d3_plain(acc, reset));
+    ICPX_TRY(stats_read_d3_prune(acc, reset));
+    if (out) std::memcpy(out, acc, sizeof(acc));
     return ICPX_OK;
 }
 #endif

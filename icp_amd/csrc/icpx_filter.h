@@ -229,7 +229,8 @@ ICPX_DEV void load_filter_block(const LdsView<D>& L, int jb, f32x4 (&tc)[D], f32
 // Workgroup-wide (contains barriers); L.gs serves as reduction scratch (>= 72 doubles).
 template <int D>
 ICPX_DEV FilterFrame stage_targets(const double* __restrict__ dst, const int m, const int m4, const int T,
-                                   const LdsView<D>& L, const bool filter) {
+                                   const LdsView<D>& L, const bool filter,
+                                   const uint16_t* __restrict__ perm = nullptr) {
     const int tid = threadIdx.x;
     double lo[D], hi[D];
 #pragma unroll
@@ -241,7 +242,8 @@ ICPX_DEV FilterFrame stage_targets(const double* __restrict__ dst, const int m, 
     for (int j = tid; j < m4; j += T) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            double v = j < m ? dst[static_cast<int64_t>(j) * D + d] : __builtin_inf();
+            // perm: LDS slot j holds target perm[j] of the cloud (icpx_prune.h)
+            double v = j < m ? dst[static_cast<int64_t>(perm ? static_cast<int>(perm[j]) : j) * D + d] : __builtin_inf();
             L.t[d][j] = v;
             if (filter && j < m) {
                 t_bad = t_bad || !(__builtin_fabs(v) < 1e300);

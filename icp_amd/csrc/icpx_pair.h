@@ -20,10 +20,19 @@
 
 #include "icpx_filter.h"
 #include "icpx_math.h"
+#include "icpx_prune.h"
 
 namespace icpx {
 
 constexpr int kPairMaxN = 4096;
+constexpr size_t kPairMaxLds = 160 * 1024 - 256;  // dynamic LDS budget (the kernel keeps a few static words)
+
+// launch geometry of the fused kernel, chosen by the host (icpx_capi.hip: fused_fits)
+struct PairLaunch {
+    int qpt, threads;
+    size_t lds;
+    int cus;      // compute units of the device
+};
 constexpr int kGsStride = 64;   // level-1 group sums per value
 constexpr int kGsValues = 10;   // up to 9 covariance terms (+ spare)
 constexpr int kBcDoubles = 48;  // broadcast area
@@ -62,6 +71,12 @@ struct PairBatch {
     // packed-f32 candidate filter in front of the exact f64 search (nn_filtered below)
     int32_t use_filter;        // the launch reserved the f32 target copy in LDS
     int32_t* seeds;            // n_total: previous nearest neighbour by point, carried between launches / tasks; may be nullptr
+    // pruned search (icpx_prune.h): Morton orders of the clouds (pair_perm_kernel) and the exchange
+    // buffer between the lanes that search (sorted order) and the lanes that own the points; with
+    // these set, `seeds` holds LDS slots (sorted order) instead of cloud indices.  All null = off
+    const uint16_t* sperm;     // n_total: source point at sorted position r of its pair
+    const uint16_t* tperm;     // m_total: target at LDS slot j of its pair
+    double* xbest;             // n_total: d2 of the neighbour, by point
 };
 
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
@@ -91,8 +106,10 @@ ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap, int filter) {
     return v;
 }
 
-inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter) {
-    return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0);
+// prune: tcap must be a multiple of kPruneBlk; the boxes follow the f32 copy
+inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter, bool prune = false) {
+    return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0) +
+           (prune ? sizeof(float) * 2 * static_cast<size_t>(dim) * (tcap / kPruneBlk) : 0);
 }
 
 // TREE64 sum of NV values per point.  f(k, vals) fills the NV contributions of point tid + k*T
@@ -251,9 +268,176 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
     __syncthreads();  // hist may be reused by the caller
 }
 
+// Pre-pass of the pruned search: Morton order of every cloud of a batch.  grid (n_pairs, 2): y = 0
+// source clouds -> sperm, y = 1 target clouds -> tperm.  Dynamic LDS: npad_cap * 12 + 512 bytes.
+// Only the QUALITY of the pruning depends on this order, never the result (icpx_prune.h), so
+// non-finite coordinates simply land in cell 0.
+template <int D>
+__global__ void __launch_bounds__(512)
+pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src_off, const double* __restrict__ dst,
+                 const int64_t* __restrict__ dst_off, uint16_t* __restrict__ sperm, uint16_t* __restrict__ tperm,
+                 int npad_cap) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const bool is_t = blockIdx.y == 1;
+    const int64_t* off = is_t ? dst_off : src_off;
+    const int64_t o0 = off[blockIdx.x];
+    const int cnt = static_cast<int>(off[blockIdx.x + 1] - o0);
+    if (cnt <= 0) return;
+    const double* __restrict__ pts = (is_t ? dst : src) + o0 * D;
+    uint16_t* __restrict__ out = (is_t ? tperm : sperm) + o0;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
+    int npad = 2;
+    while (npad < cnt) npad <<= 1;
+    uint64_t* key = reinterpret_cast<uint64_t*>(lds_raw);
+    uint32_t* val = reinterpret_cast<uint32_t*>(key + npad_cap);
+    double* red = reinterpret_cast<double*>(val + npad_cap);
+    double lo[D], hi[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        lo[d] = __builtin_inf();
+        hi[d] = -__builtin_inf();
+    }
+    for (int i = tid; i < cnt; i += T)
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            double v = pts[static_cast<int64_t>(i) * D + d];
+            if (__builtin_fabs(v) < 1e300) {
+                lo[d] = __builtin_fmin(lo[d], v);
+                hi[d] = __builtin_fmax(hi[d], v);
+            }
+        }
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[d] = __builtin_fmin(lo[d], __shfl_xor(lo[d], o));
+            hi[d] = __builtin_fmax(hi[d], __shfl_xor(hi[d], o));
+        }
+        if (lane == 0) {
+            red[wave * 8 + d] = lo[d];
+            red[wave * 8 + 4 + d] = hi[d];
+        }
+    }
+    __syncthreads();
+    constexpr double QMAX = D == 3 ? 1023.0 : 65535.0;
+    double scale[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        double l = __builtin_inf(), h = -__builtin_inf();
+        for (int w = 0; w < W; w++) {
+            l = __builtin_fmin(l, red[w * 8 + d]);
+            h = __builtin_fmax(h, red[w * 8 + 4 + d]);
+        }
+        lo[d] = l;
+        scale[d] = h > l ? QMAX / (h - l) : 0.0;
+    }
+    for (int i = tid; i < npad; i += T) {
+        uint64_t code = ~0ULL;
+        if (i < cnt) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                double x = (pts[static_cast<int64_t>(i) * D + d] - lo[d]) * scale[d];
+                x = __builtin_fmin(__builtin_fmax(x, 0.0), QMAX);  // NaN -> 0
+                uint32_t u = static_cast<uint32_t>(x);
+                c |= (D == 3 ? spread3(u) : spread2(u)) << d;
+            }
+            code = c;
+        }
+        key[i] = code;
+        val[i] = static_cast<uint32_t>(i);
+    }
+    __syncthreads();
+    bitonic_sort(key, val, npad, T);
+    for (int r = tid; r < cnt; r += T) out[r] = static_cast<uint16_t>(val[r]);
+}
+
+// Correspondence step of the pruned mode.  The lanes take the queries in sorted order (lane tid,
+// slot k <-> sorted position tid + k*T, source point sp[k]), search, and hand (d2, slot) back to
+// the lanes that own the points through pb.xbest / pb.seeds; `sslot` carries the seeds between
+// iterations.  Workgroup-wide.
+template <int D, int QPT>
+ICPX_DEV void pruned_search(const PairBatch& pb, const double* __restrict__ src, const int64_t s0,
+                            const Xf<D>& X, const int (&sp)[QPT], int (&sslot)[QPT], const bool (&valid)[QPT],
+                            const bool seeded, const LdsView<D>& L, const PruneView& P, const FilterFrame& F,
+                            const int m, const int m4, double (&best)[QPT], int (&pair)[QPT]) {
+    const int T = blockDim.x, tid = threadIdx.x;
+#ifdef ICPX_STATS
+    const uint64_t ts0 = wall_clock64();
+    uint64_t st_slot = 0;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // pb.cur of the step before (a barrier lies between)
+    XfRows<D> xr = xf_rows<D>(X);
+    auto load_query = [&](int k, double (&qq)[D]) {
+        double pnt[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            double v = 0.0;
+            if (valid[k]) v = D == 2 ? src[static_cast<int64_t>(sp[k]) * D + d] : pb.cur[(s0 + sp[k]) * D + d];
+            pnt[d] = v;
+        }
+        if (D == 2) {
+            xf_apply<D>(xr, pnt, qq);  // a_current = transform * a (trimmed.cpp:49)
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; d++) qq[d] = pnt[d];
+        }
+    };
+    if (seeded) {
+        // one slot at a time: only one query per lane is live while the wave walks its blocks
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            double qq[D];
+            load_query(k, qq);
+            const double (&q1)[1][D] = reinterpret_cast<const double (&)[1][D]>(qq);
+            double b1[1];
+            int s1[1] = {sslot[k]};
+            seed_bound<D, 1>(q1, L, m, b1, s1);
+#ifdef ICPX_STATS
+            const uint64_t tp0 = wall_clock64();
+#endif
+            nn_pruned_slot<D>(qq, valid[k], L, P, F, b1[0], s1[0]);
+#ifdef ICPX_STATS
+            st_slot += wall_clock64() - tp0;
+#endif
+            sslot[k] = s1[0];
+            if (valid[k]) {
+                pb.seeds[s0 + sp[k]] = s1[0];
+                pb.xbest[s0 + sp[k]] = b1[0];
+            }
+        }
+    } else {
+        double q[QPT][D], sb[QPT];
+#pragma unroll
+        for (int k = 0; k < QPT; k++) load_query(k, q[k]);
+        nn_twomin_p<D, QPT>(q, L, m4, P, F, sb, sslot);
+#pragma unroll
+        for (int k = 0; k < QPT; k++)
+            if (valid[k]) {
+                pb.seeds[s0 + sp[k]] = sslot[k];
+                pb.xbest[s0 + sp[k]] = sb[k];
+            }
+    }
+#ifdef ICPX_STATS
+    if (seeded && (threadIdx.x >> 6) == 0) {  // wave 0 of every workgroup, seeded calls only
+        ICPX_STAT(13, st_slot);
+        ICPX_STAT(14, wall_clock64() - ts0);
+        ICPX_STAT(15, 1);
+    }
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        pair[k] = valid[k] ? pb.seeds[s0 + tid + k * T] : 0;
+        best[k] = valid[k] ? pb.xbest[s0 + tid + k * T] : 0.0;
+    }
+}
+
 // One visit of pair p: optional begin()/setup(), then up to max_steps iterations of the converge
 // loop.  Returns 1 when should_terminate fired (pair finished), 2 when it paused at max_steps.
-template <int D, int METHOD, int QPT>
+template <int D, int METHOD, int QPT, bool PRUNE>
 ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps,
                        double* lds_raw) {
     constexpr int L1 = D + 1;
@@ -266,13 +450,45 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     const double* __restrict__ src = pb.src + s0 * D;
     const double* __restrict__ dst = pb.dst + d0 * D;
     PairState* st = pb.states + p;
-    const bool filter = pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
+    // PRUNE kernels are only launched with the filter's LDS reserved and the permutations computed
+    const bool filter = PRUNE || (pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA));
     LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
     const bool empty = (n == 0 || m == 0);
+    // pruned search (icpx_prune.h): both clouds in Morton order, a bounding box per 16 targets
+    constexpr bool prune = PRUNE;
+    PruneView P;
+    if (prune) {
+        float* bx = L.tf[D - 1] + pb.lds_target_cap;
+        const int nbcap = pb.lds_target_cap / kPruneBlk;
+        for (int d = 0; d < D; d++) {
+            P.lo[d] = bx + d * nbcap;
+            P.hi[d] = bx + (D + d) * nbcap;
+        }
+        P.nb = (m + kPruneBlk - 1) / kPruneBlk;
+        P.tperm = pb.tperm + d0;
+        P.m = m;
+    }
 
     // ---- stage the target cloud into LDS as SoA (+ f32 copy about the bounding-box centre) ----
-    const int m4 = (m + 3) & ~3;
-    const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter);
+    const int m4 = prune ? (m + kPruneBlk - 1) & ~(kPruneBlk - 1) : (m + 3) & ~3;
+    const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter, prune ? P.tperm : nullptr);
+    if (prune) {
+        for (int b = tid; b < P.nb; b += T)
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                float lo = __builtin_inff(), hi = -__builtin_inff();
+                for (int u = 0; u < kPruneBlk; u++) {
+                    const int j = b * kPruneBlk + u;
+                    if (j < m) {
+                        lo = __builtin_fminf(lo, L.tf[d][j]);
+                        hi = __builtin_fmaxf(hi, L.tf[d][j]);
+                    }
+                }
+                P.lo[d][b] = lo;
+                P.hi[d][b] = hi;
+            }
+        __syncthreads();
+    }
 
     // ---- per-thread point slots ----
     double a[QPT][D];    // 2D: source points; 3D: running cloud c
@@ -289,11 +505,21 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         for (int d = 0; d < D; d++) {
             double v = 0.0;
             if (valid[k]) {
-                if (D == 3 && !do_setup) v = pb.cur[(s0 + i) * D + d];
+                if (D == 3 && !do_setup) v = prune ? 0.0 : pb.cur[(s0 + i) * D + d];
                 else v = src[static_cast<int64_t>(i) * D + d];
             }
             a[k][d] = v;
+            // pruned 3D: the running cloud lives in pb.cur only (the search lanes gather from it)
+            if (D == 3 && prune && do_setup && valid[k]) pb.cur[(s0 + i) * D + d] = v;
         }
+    }
+    if (D == 3 && prune) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+
+    int sp[QPT], sslot[QPT];  // pruned mode: source point / seed slot of sorted position tid + k*T
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        sp[k] = (prune && valid[k]) ? static_cast<int>(pb.sperm[s0 + tid + k * T]) : 0;
+        sslot[k] = 0;
     }
 
     // ---- state ----
@@ -321,6 +547,10 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     if (filter && !do_setup && pb.seeds && !empty && (D == 2 || st->iteration_count > 0)) {
 #pragma unroll
         for (int k = 0; k < QPT; k++) pair[k] = valid[k] ? pb.seeds[s0 + tid + k * T] : 0;
+        if (prune) {
+#pragma unroll
+            for (int k = 0; k < QPT; k++) sslot[k] = valid[k] ? pb.seeds[s0 + sp[k]] : 0;
+        }
         have_seed = true;
     }
 
@@ -348,7 +578,8 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
+            if (prune) pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, false, L, P, F, m, m4, best, pair);
+            else if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
             else nn_lds<D, QPT>(q, L, m4, best, pair);
             have_seed = filter;
 #pragma unroll
@@ -430,7 +661,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
-                    if (have_seed) {
+                    if (prune) {
+                        pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, F, m, m4, best, pair);
+                    } else if (have_seed) {
                         seed_bound<D, QPT>(cur, L, m, best, pair);
                         nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
                     } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
@@ -466,12 +699,20 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 }
             } else {
                 // 3D: nearest_neighbor(c), vanilla_3d.cpp:30-45
-#pragma unroll
-                for (int k = 0; k < QPT; k++)
-#pragma unroll
-                    for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 double best[QPT];
-                if (have_seed) {
+                if (!prune) {
+#pragma unroll
+                    for (int k = 0; k < QPT; k++)
+#pragma unroll
+                        for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
+                }
+                if (prune) {
+                    pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, F, m, m4, best, pair);
+#pragma unroll
+                    for (int k = 0; k < QPT; k++)
+#pragma unroll
+                        for (int d = 0; d < D; d++) cur[k][d] = valid[k] ? pb.cur[(s0 + tid + k * T) * D + d] : 0.0;
+                } else if (have_seed) {
                     seed_bound<D, QPT>(cur, L, m, best, pair);
                     nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
                 } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
@@ -549,7 +790,18 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int e = 0; e < XN; e++) S.m[e] = L.bc[16 + e];
                 XfRows<D> sr = xf_rows<D>(S);
 #pragma unroll
-                for (int k = 0; k < QPT; k++) xf_apply<D>(sr, cur[k], a[k]);
+                for (int k = 0; k < QPT; k++) {
+                    if (prune) {
+                        double nc[D];
+                        xf_apply<D>(sr, cur[k], nc);
+                        if (valid[k])
+#pragma unroll
+                            for (int d = 0; d < D; d++) pb.cur[(s0 + tid + k * T) * D + d] = nc[d];
+                    } else {
+                        xf_apply<D>(sr, cur[k], a[k]);
+                    }
+                }
+                if (prune) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
             if (D == 2 && METHOD == ICPX_TRIMMED) state_cost = __builtin_sqrt(s1[2 * D] / static_cast<double>(n));
             __syncthreads();
@@ -567,7 +819,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         for (int k = 0; k < QPT; k++)
             if (valid[k]) pb.seeds[s0 + tid + k * T] = pair[k];
     }
-    if (D == 3 && pb.cur) {
+    if (D == 3 && pb.cur && !prune) {
 #pragma unroll
         for (int k = 0; k < QPT; k++)
             if (valid[k])
@@ -580,7 +832,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 #pragma unroll
             for (int k = 0; k < QPT; k++)
                 if (valid[k]) {
-                    pb.m_pair[s0 + tid + k * T] = pair[k];
+                    pb.m_pair[s0 + tid + k * T] = prune ? static_cast<int>(P.tperm[pair[k]]) : pair[k];
                     pb.m_cost[s0 + tid + k * T] = cost[k];
                     pb.m_point[s0 + tid + k * T] = tid + k * T;
                 }
@@ -589,7 +841,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             for (int k = 0; k < QPT; k++)
                 if (valid[k]) {
                     pb.m_point[s0 + tid + k * T] = tid + k * T;
-                    pb.m_pair[s0 + tid + k * T] = pair[k];
+                    pb.m_pair[s0 + tid + k * T] = prune ? static_cast<int>(P.tperm[pair[k]]) : pair[k];
                     pb.m_cost[s0 + tid + k * T] = cost[k];
                 }
         } else {
@@ -604,7 +856,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             for (int k = 0; k < QPT; k++)
                 if (valid[k]) {
                     L.skey[tid + k * T] = static_cast<uint64_t>(__double_as_longlong(cost[k]));
-                    pb.pair_tmp[s0 + tid + k * T] = pair[k];
+                    pb.pair_tmp[s0 + tid + k * T] = prune ? static_cast<int>(P.tperm[pair[k]]) : pair[k];
                 }
             __syncthreads();
             bitonic_sort(L.skey, L.sval, npad, T);
@@ -634,11 +886,11 @@ constexpr int pair_min_waves(int d, int qpt, int tmax) {
     return tmax > 256 ? 1 : (d == 2 ? (qpt <= 2 ? 4 : (qpt <= 4 ? 3 : 1)) : (qpt <= 4 ? ICPX_3D_SMALL_WAVES : 1));
 }
 
-template <int D, int METHOD, int QPT, int TMAX>
+template <int D, int METHOD, int QPT, int TMAX, bool PRUNE>
 __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kernel(const PairBatch pb) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     if (pb.sched_state == nullptr) {
-        pair_body<D, METHOD, QPT>(pb, blockIdx.x, pb.do_setup, pb.max_steps, lds_raw);
+        pair_body<D, METHOD, QPT, PRUNE>(pb, blockIdx.x, pb.do_setup, pb.max_steps, lds_raw);
         return;
     }
     // ---- persistent workgroup: iteration-granular tasks ----
@@ -711,7 +963,7 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
 #ifdef ICPX_STATS
         const uint64_t stat_t0 = wall_clock64();
 #endif
-        const int code = pair_body<D, METHOD, QPT>(pb, q, pick & 1, task_steps, lds_raw);
+        const int code = pair_body<D, METHOD, QPT, PRUNE>(pb, q, pick & 1, task_steps, lds_raw);
 #ifdef ICPX_STATS
         if (tid == 0) {
             atomicAdd(&g_icpx_stats[5], static_cast<unsigned long long>(wall_clock64() - stat_t0));  // busy ticks
