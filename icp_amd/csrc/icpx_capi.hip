@@ -149,13 +149,12 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
     r.filter = !(dim == 2 && method == ICPX_VANILLA) && !(fe && fe[0] == '0') &&
                pair_lds_bytes(dim, r.tcap, r.scap, true) <= kMaxLds;
     r.prune = false;
-    if (allow_prune && r.filter && m >= 128 && m < 65536) {
-        // development override: ICPX_PRUNE=0
+    if (allow_prune && !(dim == 2 && method == ICPX_VANILLA) && m >= 128 && m < 65536) {
+        // grid-pruned search (icpx_prune.h); development override: ICPX_PRUNE=0
         const char* pe = std::getenv("ICPX_PRUNE");
-        const int tcap16 = (r.tcap + kPruneBlk - 1) & ~(kPruneBlk - 1);
-        if (!(pe && pe[0] == '0') && pair_lds_bytes(dim, tcap16, r.scap, true, true) <= kMaxLds) {
+        if (!(pe && pe[0] == '0') && pair_lds_bytes(dim, r.tcap, r.scap, false, true) <= kMaxLds) {
             r.prune = true;
-            r.tcap = tcap16;
+            r.filter = false;  // no f32 copy in LDS
         }
     }
     r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter, r.prune);
@@ -178,7 +177,7 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     pl.threads = g.threads;
     pl.lds = g.lds;
     pl.cus = di->cus;
-    const bool prune = g.prune && pb.sperm && pb.tperm && pb.xbest && pb.seeds;
+    const bool prune = g.prune && pb.sperm && pb.tperm && pb.xbest && pb.seeds && pb.grids && pb.cstart;
     if (g.prune && !prune) return fail(ICPX_ERR_INVALID, "pruned launch without its permutation buffers");
     if (pb.dim == 2) return prune ? launch_pairs_d2_prune(pb, n_pairs, pl, stream) : launch_pairs_d2_plain(pb, n_pairs, pl, stream);
     return prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream);
@@ -194,7 +193,7 @@ icpx_criteria no_criteria() {
 struct Workspace {
     std::mutex mu;
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
-    DevBuf sperm, tperm, xbest;  // pruned search of the batch entry point
+    DevBuf sperm, tperm, xbest, grids, cstart;  // pruned search of the batch entry point
     GridIndex* grid = nullptr;  // grow-only uniform-grid index of the stand-alone queries
 };
 Workspace& workspace(int device) {
@@ -630,7 +629,7 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
         ICPX_TRY(ws.cur.reserve(sizeof(double) * 3 * (n_total > 0 ? n_total : 1)));
         pb.cur = ws.cur.as<double>();
     }
-    if (geom.filter) {
+    if (geom.filter || geom.prune) {
         // previous nearest neighbours: the filtered search's seeds travel with the pair too
         ICPX_TRY(ws.seeds.reserve(sizeof(int32_t) * (n_total > 0 ? n_total : 1)));
         pb.seeds = ws.seeds.as<int32_t>();
@@ -640,6 +639,8 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
         ICPX_TRY(ws.sperm.reserve(sizeof(uint16_t) * (n_total > 0 ? n_total : 1)));
         ICPX_TRY(ws.tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
         ICPX_TRY(ws.xbest.reserve(sizeof(double) * (n_total > 0 ? n_total : 1)));
+        ICPX_TRY(ws.grids.reserve(sizeof(PairGrid) * n_pairs));
+        ICPX_TRY(ws.cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
         const int npad = next_pow2(static_cast<int>(n_max > m_max ? n_max : m_max));
         const size_t perm_lds = static_cast<size_t>(npad) * 12 + 512;
         if (perm_lds > kMaxLds) return fail(ICPX_ERR_UNSUPPORTED, "permutation pre-pass: cloud too large");
@@ -656,11 +657,13 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
         }
         hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs), 2), dim3(npad >= 2048 ? 512 : 256), perm_lds, stream,
                            d_src, ws.soff.as<int64_t>(), d_dst, ws.doff.as<int64_t>(), ws.sperm.as<uint16_t>(),
-                           ws.tperm.as<uint16_t>(), npad);
+                           ws.tperm.as<uint16_t>(), ws.grids.as<PairGrid>(), ws.cstart.as<uint16_t>(), npad);
         ICPX_HIP(hipGetLastError());
         pb.sperm = ws.sperm.as<uint16_t>();
         pb.tperm = ws.tperm.as<uint16_t>();
         pb.xbest = ws.xbest.as<double>();
+        pb.grids = ws.grids.as<PairGrid>();
+        pb.cstart = ws.cstart.as<uint16_t>();
     }
     pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ICPX_TRY(launch_pairs(pb, n_pairs, geom, stream));

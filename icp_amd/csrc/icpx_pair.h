@@ -77,6 +77,8 @@ struct PairBatch {
     const uint16_t* sperm;     // n_total: source point at sorted position r of its pair
     const uint16_t* tperm;     // m_total: target at LDS slot j of its pair
     double* xbest;             // n_total: d2 of the neighbour, by point
+    const PairGrid* grids;     // n_pairs: grid of every target cloud
+    const uint16_t* cstart;    // n_pairs x kGridTable: cell start tables
 };
 
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
@@ -106,10 +108,10 @@ ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap, int filter) {
     return v;
 }
 
-// prune: tcap must be a multiple of kPruneBlk; the boxes follow the f32 copy
+// prune (grid-pruned search, icpx_prune.h): no f32 copy; the cell start table takes its place
 inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter, bool prune = false) {
-    return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0) +
-           (prune ? sizeof(float) * 2 * static_cast<size_t>(dim) * (tcap / kPruneBlk) : 0);
+    if (prune) return pair_lds_filter_offset(dim, tcap, scap) + sizeof(uint16_t) * kGridTable;
+    return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0);
 }
 
 // TREE64 sum of NV values per point.  f(k, vals) fills the NV contributions of point tid + k*T
@@ -268,24 +270,36 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
     __syncthreads();  // hist may be reused by the caller
 }
 
-// Pre-pass of the pruned search: Morton order of every cloud of a batch.  grid (n_pairs, 2): y = 0
-// source clouds -> sperm, y = 1 target clouds -> tperm.  Dynamic LDS: npad_cap * 12 + 512 bytes.
-// Only the QUALITY of the pruning depends on this order, never the result (icpx_prune.h), so
-// non-finite coordinates simply land in cell 0.
+// Pre-pass of the pruned search, one workgroup per cloud of a batch.  grid (n_pairs, 2):
+//   y = 0  source cloud -> sperm: Morton order (the lanes of a wave then search nearby queries)
+//   y = 1  target cloud -> its grid (PairGrid), tperm: order by cell, cstart: cell start table
+// Dynamic LDS: npad_cap * 12 + 512 bytes.  The source order only affects speed; the target
+// order, table and grid parameters are what the search's exactness argument rests on.
 template <int D>
 __global__ void __launch_bounds__(512)
 pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src_off, const double* __restrict__ dst,
                  const int64_t* __restrict__ dst_off, uint16_t* __restrict__ sperm, uint16_t* __restrict__ tperm,
-                 int npad_cap) {
+                 PairGrid* __restrict__ grids, uint16_t* __restrict__ cstart, int npad_cap) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const bool is_t = blockIdx.y == 1;
     const int64_t* off = is_t ? dst_off : src_off;
     const int64_t o0 = off[blockIdx.x];
     const int cnt = static_cast<int>(off[blockIdx.x + 1] - o0);
-    if (cnt <= 0) return;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
+    uint16_t* __restrict__ table = cstart + static_cast<int64_t>(blockIdx.x) * kGridTable;
+    if (cnt <= 0) {
+        if (is_t) {
+            if (tid == 0) {
+                PairGrid g{};
+                g.G = 1;
+                grids[blockIdx.x] = g;
+            }
+            for (int c = tid; c < kGridTable; c += T) table[c] = 0;
+        }
+        return;
+    }
     const double* __restrict__ pts = (is_t ? dst : src) + o0 * D;
     uint16_t* __restrict__ out = (is_t ? tperm : sperm) + o0;
-    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
     int npad = 2;
     while (npad < cnt) npad <<= 1;
     uint64_t* key = reinterpret_cast<uint64_t*>(lds_raw);
@@ -297,13 +311,16 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
         lo[d] = __builtin_inf();
         hi[d] = -__builtin_inf();
     }
+    bool bad = false;
     for (int i = tid; i < cnt; i += T)
 #pragma unroll
         for (int d = 0; d < D; d++) {
             double v = pts[static_cast<int64_t>(i) * D + d];
-            if (__builtin_fabs(v) < 1e300) {
+            if (__builtin_fabs(v) < 1e150) {
                 lo[d] = __builtin_fmin(lo[d], v);
                 hi[d] = __builtin_fmax(hi[d], v);
+            } else {
+                bad = true;
             }
         }
 #pragma unroll
@@ -318,9 +335,13 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
             red[wave * 8 + 4 + d] = hi[d];
         }
     }
+    const bool wave_bad = __any(bad);
+    if (lane == 0) red[wave * 8 + 3] = wave_bad ? 1.0 : 0.0;
     __syncthreads();
-    constexpr double QMAX = D == 3 ? 1023.0 : 65535.0;
+    const int G = is_t ? grid_cells_per_axis(D, cnt) : (D == 3 ? 1024 : 65536);
     double scale[D];
+    bool any_bad = false;
+    for (int w = 0; w < W; w++) any_bad = any_bad || red[w * 8 + 3] != 0.0;
 #pragma unroll
     for (int d = 0; d < D; d++) {
         double l = __builtin_inf(), h = -__builtin_inf();
@@ -328,19 +349,38 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
             l = __builtin_fmin(l, red[w * 8 + d]);
             h = __builtin_fmax(h, red[w * 8 + 4 + d]);
         }
+        if (!(l <= h)) {  // no usable coordinate on this axis
+            l = 0.0;
+            h = 0.0;
+        }
         lo[d] = l;
-        scale[d] = h > l ? QMAX / (h - l) : 0.0;
+        scale[d] = h > l ? static_cast<double>(G) / (h - l) : 0.0;
+        if (!(scale[d] < 1e300)) scale[d] = 0.0;
+    }
+    if (is_t && tid == 0) {
+        PairGrid g{};
+        for (int d = 0; d < D; d++) {
+            g.lo[d] = lo[d];
+            g.scale[d] = scale[d];
+        }
+        g.G = G;
+        g.bad = any_bad ? 1 : 0;
+        grids[blockIdx.x] = g;
     }
     for (int i = tid; i < npad; i += T) {
         uint64_t code = ~0ULL;
         if (i < cnt) {
             uint32_t c = 0;
+            if (is_t) {
+                // cell id, x fastest — the function the search evaluates for the queries
+                for (int d = D - 1; d >= 0; d--)
+                    c = c * G + static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G));
+            } else {
 #pragma unroll
-            for (int d = 0; d < D; d++) {
-                double x = (pts[static_cast<int64_t>(i) * D + d] - lo[d]) * scale[d];
-                x = __builtin_fmin(__builtin_fmax(x, 0.0), QMAX);  // NaN -> 0
-                uint32_t u = static_cast<uint32_t>(x);
-                c |= (D == 3 ? spread3(u) : spread2(u)) << d;
+                for (int d = 0; d < D; d++) {
+                    uint32_t u = static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G));
+                    c |= (D == 3 ? spread3(u) : spread2(u)) << d;
+                }
             }
             code = c;
         }
@@ -350,6 +390,17 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
     __syncthreads();
     bitonic_sort(key, val, npad, T);
     for (int r = tid; r < cnt; r += T) out[r] = static_cast<uint16_t>(val[r]);
+    if (is_t) {
+        int ncell = G;
+        for (int d = 1; d < D; d++) ncell *= G;
+        for (int r = tid; r < cnt; r += T) {
+            const int cur = static_cast<int>(key[r]);
+            const int prev = r > 0 ? static_cast<int>(key[r - 1]) : -1;
+            for (int c = prev + 1; c <= cur; c++) table[c] = static_cast<uint16_t>(r);
+            if (r == cnt - 1)
+                for (int c = cur + 1; c <= ncell; c++) table[c] = static_cast<uint16_t>(cnt);
+        }
+    }
 }
 
 // Correspondence step of the pruned mode.  The lanes take the queries in sorted order (lane tid,
@@ -359,8 +410,8 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
 template <int D, int QPT>
 ICPX_DEV void pruned_search(const PairBatch& pb, const double* __restrict__ src, const int64_t s0,
                             const Xf<D>& X, const int (&sp)[QPT], int (&sslot)[QPT], const bool (&valid)[QPT],
-                            const bool seeded, const LdsView<D>& L, const PruneView& P, const FilterFrame& F,
-                            const int m, const int m4, double (&best)[QPT], int (&pair)[QPT]) {
+                            const bool seeded, const LdsView<D>& L, const GridView& P,
+                            const int m, double (&best)[QPT], int (&pair)[QPT]) {
     const int T = blockDim.x, tid = threadIdx.x;
 #ifdef ICPX_STATS
     const uint64_t ts0 = wall_clock64();
@@ -368,7 +419,10 @@ ICPX_DEV void pruned_search(const PairBatch& pb, const double* __restrict__ src,
 #endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // pb.cur of the step before (a barrier lies between)
     XfRows<D> xr = xf_rows<D>(X);
-    auto load_query = [&](int k, double (&qq)[D]) {
+    // all queries first (their gathers overlap), then one slot at a time
+    double q[QPT][D];
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
         double pnt[D];
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -377,49 +431,36 @@ ICPX_DEV void pruned_search(const PairBatch& pb, const double* __restrict__ src,
             pnt[d] = v;
         }
         if (D == 2) {
-            xf_apply<D>(xr, pnt, qq);  // a_current = transform * a (trimmed.cpp:49)
+            xf_apply<D>(xr, pnt, q[k]);  // a_current = transform * a (trimmed.cpp:49)
         } else {
 #pragma unroll
-            for (int d = 0; d < D; d++) qq[d] = pnt[d];
+            for (int d = 0; d < D; d++) q[k][d] = pnt[d];
         }
-    };
-    if (seeded) {
-        // one slot at a time: only one query per lane is live while the wave walks its blocks
+    }
 #pragma unroll
-        for (int k = 0; k < QPT; k++) {
-            double qq[D];
-            load_query(k, qq);
+    for (int k = 0; k < QPT; k++) {
+        const double (&qq)[D] = q[k];
+        double b1[1] = {0.0};
+        int s1[1] = {sslot[k]};
+        if (seeded) {
             const double (&q1)[1][D] = reinterpret_cast<const double (&)[1][D]>(qq);
-            double b1[1];
-            int s1[1] = {sslot[k]};
             seed_bound<D, 1>(q1, L, m, b1, s1);
-#ifdef ICPX_STATS
-            const uint64_t tp0 = wall_clock64();
-#endif
-            nn_pruned_slot<D>(qq, valid[k], L, P, F, b1[0], s1[0]);
-#ifdef ICPX_STATS
-            st_slot += wall_clock64() - tp0;
-#endif
-            sslot[k] = s1[0];
-            if (valid[k]) {
-                pb.seeds[s0 + sp[k]] = s1[0];
-                pb.xbest[s0 + sp[k]] = b1[0];
-            }
         }
-    } else {
-        double q[QPT][D], sb[QPT];
-#pragma unroll
-        for (int k = 0; k < QPT; k++) load_query(k, q[k]);
-        nn_twomin_p<D, QPT>(q, L, m4, P, F, sb, sslot);
-#pragma unroll
-        for (int k = 0; k < QPT; k++)
-            if (valid[k]) {
-                pb.seeds[s0 + sp[k]] = sslot[k];
-                pb.xbest[s0 + sp[k]] = sb[k];
-            }
+#ifdef ICPX_STATS
+        const uint64_t tp0 = wall_clock64();
+#endif
+        nn_grid_slot<D>(qq, valid[k], seeded, L, P, b1[0], s1[0]);
+#ifdef ICPX_STATS
+        st_slot += wall_clock64() - tp0;
+#endif
+        sslot[k] = s1[0];
+        if (valid[k]) {
+            pb.seeds[s0 + sp[k]] = s1[0];
+            pb.xbest[s0 + sp[k]] = b1[0];
+        }
     }
 #ifdef ICPX_STATS
-    if (seeded && (threadIdx.x >> 6) == 0) {  // wave 0 of every workgroup, seeded calls only
+    if ((threadIdx.x >> 6) == 0) {  // wave 0 of every workgroup
         ICPX_STAT(13, st_slot);
         ICPX_STAT(14, wall_clock64() - ts0);
         ICPX_STAT(15, 1);
@@ -450,45 +491,28 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     const double* __restrict__ src = pb.src + s0 * D;
     const double* __restrict__ dst = pb.dst + d0 * D;
     PairState* st = pb.states + p;
-    // PRUNE kernels are only launched with the filter's LDS reserved and the permutations computed
-    const bool filter = PRUNE || (pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA));
-    LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
-    const bool empty = (n == 0 || m == 0);
-    // pruned search (icpx_prune.h): both clouds in Morton order, a bounding box per 16 targets
+    // PRUNE kernels (batches): grid-pruned search, no f32 copy; `filter` then only stands for "the
+    // search is seeded by the previous neighbours"
     constexpr bool prune = PRUNE;
-    PruneView P;
+    const bool filter = PRUNE || (pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA));
+    LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter && !prune);
+    const bool empty = (n == 0 || m == 0);
+    GridView P;
     if (prune) {
-        float* bx = L.tf[D - 1] + pb.lds_target_cap;
-        const int nbcap = pb.lds_target_cap / kPruneBlk;
-        for (int d = 0; d < D; d++) {
-            P.lo[d] = bx + d * nbcap;
-            P.hi[d] = bx + (D + d) * nbcap;
-        }
-        P.nb = (m + kPruneBlk - 1) / kPruneBlk;
+        uint16_t* table = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(lds_raw) +
+                                                      pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap));
+        P.g = pb.grids[p];
+        int ncell = P.g.G;
+        for (int d = 1; d < D; d++) ncell *= P.g.G;
+        for (int c = tid; c <= ncell; c += T) table[c] = pb.cstart[static_cast<int64_t>(p) * kGridTable + c];
+        P.cstart = table;
         P.tperm = pb.tperm + d0;
         P.m = m;
     }
 
     // ---- stage the target cloud into LDS as SoA (+ f32 copy about the bounding-box centre) ----
-    const int m4 = prune ? (m + kPruneBlk - 1) & ~(kPruneBlk - 1) : (m + 3) & ~3;
-    const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter, prune ? P.tperm : nullptr);
-    if (prune) {
-        for (int b = tid; b < P.nb; b += T)
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                float lo = __builtin_inff(), hi = -__builtin_inff();
-                for (int u = 0; u < kPruneBlk; u++) {
-                    const int j = b * kPruneBlk + u;
-                    if (j < m) {
-                        lo = __builtin_fminf(lo, L.tf[d][j]);
-                        hi = __builtin_fmaxf(hi, L.tf[d][j]);
-                    }
-                }
-                P.lo[d][b] = lo;
-                P.hi[d][b] = hi;
-            }
-        __syncthreads();
-    }
+    const int m4 = (m + 3) & ~3;
+    const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter && !prune, prune ? P.tperm : nullptr);
 
     // ---- per-thread point slots ----
     double a[QPT][D];    // 2D: source points; 3D: running cloud c
@@ -578,7 +602,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            if (prune) pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, false, L, P, F, m, m4, best, pair);
+            if (prune) pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, false, L, P, m, best, pair);
             else if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
             else nn_lds<D, QPT>(q, L, m4, best, pair);
             have_seed = filter;
@@ -662,7 +686,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
                     if (prune) {
-                        pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, F, m, m4, best, pair);
+                        pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, m, best, pair);
                     } else if (have_seed) {
                         seed_bound<D, QPT>(cur, L, m, best, pair);
                         nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
@@ -707,7 +731,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                         for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 }
                 if (prune) {
-                    pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, F, m, m4, best, pair);
+                    pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, m, best, pair);
 #pragma unroll
                     for (int k = 0; k < QPT; k++)
 #pragma unroll

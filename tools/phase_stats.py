@@ -18,7 +18,6 @@ tot = pairs * iters
 for nm, i in (("search", 8), ("selection", 9), ("sums", 10), ("kabsch+broadcast", 11)):
     print(f"{nm:18s} {out[i] / tot / 100:8.2f} us per pair-iteration")
 print("raw counters:", [int(out[i]) for i in range(16)])
-if out[0]:
-    print(f"seeded wave scans {out[0]}, exact flushes per scan {out[1] / out[0]:.2f}, surviving blocks per wave slot {out[12] / out[0] / max(1, -(-n // (64 * (n // 64 // max(1, n // 512) if False else 1)))):.2f} (raw per scan {out[12] / out[0]:.1f})")
 if out[15]:
-    print(f"per wave and search call: {out[14] / out[15] / 100:.1f} us in pruned_search, of which {out[13] / out[15] / 100:.1f} us in nn_pruned_slot (all slots)")
+    print(f"wave 0, per search call: {out[14] / out[15] / 100:.1f} us in pruned_search, {out[13] / out[15] / 100:.1f} us of it in nn_grid_slot; "
+          f"per grid walk: {out[12] / max(1, out[0]):.1f} steps, {out[1] / max(1, out[0]):.1f} lane-evaluations")
