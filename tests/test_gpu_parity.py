@@ -674,6 +674,67 @@ def test_batch_equals_single_pairs(icp, ob):
             assert cost[p] == ro.cost or (np.isnan(cost[p]) and np.isnan(ro.cost))
 
 
+def test_batch_grid_pruned_search_adversarial(icp, ob, monkeypatch):
+    """icpx_converge_batch searches through a per-pair LDS grid (icpx_prune.h) that must return the
+    lexicographic minimum of (d2, cloud index) whatever the geometry: exact ties and duplicates,
+    degenerate extents (collinear / planar / a single repeated point), clusters, data far from the
+    origin, sources far outside the target's box, non-finite and huge coordinates (exact scan),
+    ragged batches mixing all of these.  Checked pair by pair against the oracle, and against the
+    same batch with the grid switched off (ICPX_PRUNE=0: brute-force filter)."""
+    rng = np.random.default_rng(23)
+    crit_kw = dict(max_iterations=8, transform_tol=(1e-9, 1e-9))
+    crit = icp.make_criteria(**crit_kw)
+
+    def clouds(dim):
+        c = []
+        lat = rng.integers(0, 7, (900, dim)).astype(float)
+        c.append((lat[:700] + 0.5, lat))                                   # every distance tied many times
+        c.append((lat[:650], lat))                                         # zero distances, duplicates
+        u = rng.uniform(-5, 5, (1200, dim))
+        c.append((u[:900] * 1e-3 + 7.0e5, u * 1e-3 + 7.0e5 + 1e-4))       # far from the origin
+        line = np.zeros((800, dim)); line[:, 0] = np.linspace(-3, 3, 800); line[:, 1] = 2.0
+        c.append((rng.uniform(-4, 4, (500, dim)), line))                   # collinear target (zero extent on an axis)
+        c.append((rng.normal(size=(300, dim)), np.tile(rng.normal(size=(1, dim)), (400, 1))))  # one repeated point
+        clus = np.concatenate([rng.normal(cc, 0.01, (300, dim)) for cc in (-6.0, 0.0, 5.0)])
+        c.append((rng.uniform(-8, 8, (1000, dim)), clus))                  # clustered, most cells empty
+        c.append((rng.uniform(50, 60, (400, dim)), rng.uniform(-1, 1, (1500, dim))))  # source outside the box
+        c.append((rng.uniform(-1, 1, (1024, dim)), rng.uniform(-1, 1, (130, dim))))   # few targets
+        c.append((rng.uniform(-1, 1, (200, dim)), rng.uniform(-1, 1, (100, dim))))    # below the grid's minimum size
+        if dim == 3:
+            plane = np.concatenate([rng.uniform(-5, 5, (2000, 2)), np.zeros((2000, 1))], axis=1)
+            c.append((rng.uniform(-5, 5, (900, 3)), plane))
+        big = rng.uniform(-1, 1, (600, dim)); big[17, 0] = 1e200; big[300, 1] = -3e160
+        c.append((rng.uniform(-1, 1, (500, dim)), big))                    # huge target coordinates: exact scan
+        inf_t = rng.uniform(-1, 1, (600, dim)); inf_t[5, 0] = np.inf
+        c.append((rng.uniform(-1, 1, (500, dim)), inf_t))
+        src_bad = rng.uniform(-1, 1, (500, dim)); src_bad[9, 1] = 1e180
+        c.append((src_bad, rng.uniform(-1, 1, (700, dim))))                # one huge query in a good wave
+        return c
+
+    for dim, method in ((3, "vanilla"), (3, "trimmed"), (2, "trimmed")):
+        cs = clouds(dim)
+        so = np.cumsum([0] + [len(a) for a, _ in cs])
+        to = np.cumsum([0] + [len(b) for _, b in cs])
+        S = np.concatenate([a for a, _ in cs])
+        T = np.concatenate([b for _, b in cs])
+        with np.errstate(all="ignore"):
+            cfg = icp.Config()
+            cfg.set("max_distance", 0.8)
+            res = icp.converge_batch(dim, method, S, so, T, to, crit, cfg)
+            monkeypatch.setenv("ICPX_PRUNE", "0")
+            ref = icp.converge_batch(dim, method, S, so, T, to, crit, cfg)
+            monkeypatch.delenv("ICPX_PRUNE")
+            for x, y in zip(res, ref):
+                assert np.array_equal(x, y, equal_nan=True), (dim, method)
+            for p, (a, b) in enumerate(cs):
+                if not (np.isfinite(a).all() and np.isfinite(b).all()):
+                    continue  # the brute-force batch above is the reference there (oracle-pinned through handles)
+                ro = dev_oracle(ob, dim, method, max_distance=0.8).converge(a, b, None, ob.make_criteria(**crit_kw))
+                assert res[1][p] == ro.iteration_count, (dim, method, p)
+                assert np.array_equal(res[2][p], ro.transform, equal_nan=True), (dim, method, p)
+                assert res[0][p] == ro.cost or (np.isnan(res[0][p]) and np.isnan(ro.cost)), (dim, method, p)
+
+
 def test_batch_iteration_granular_scheduler_is_bit_identical(icp, monkeypatch):
     """Batches whose pairs slightly outnumber the resident workgroups run through persistent
     workgroups that hand pairs over between iterations (agent-scope release/acquire).  Forced on
