@@ -48,6 +48,10 @@ int launch_one(const PairBatch& pb_in, int64_t n_pairs, const PairLaunch& g, hip
             blocks = n_pairs < resident ? n_pairs : resident;
             pb.n_pairs = static_cast<int32_t>(n_pairs);
             pb.sched_steps = 1;
+            if (const char* ss = std::getenv("ICPX_SCHED_STEPS")) {  // development override
+                const int v = std::atoi(ss);
+                if (v >= 1 && v <= 64) pb.sched_steps = v;
+            }
             ICPX_HIP(hipMemsetAsync(pb.sched_state, 0, sizeof(int32_t) * (n_pairs + 1), stream));
             pb.sched_done = pb.sched_state + n_pairs;
         } else {
@@ -70,8 +74,9 @@ int launch_dm(const PairBatch& pb, int64_t n_pairs, const PairLaunch& g, hipStre
         case 20512: return launch_one<D, METHOD, 2, 512, PRUNE>(pb, n_pairs, g, stream);
         case 40512: return launch_one<D, METHOD, 4, 512, PRUNE>(pb, n_pairs, g, stream);
         case 80512: return launch_one<D, METHOD, 8, 512, PRUNE>(pb, n_pairs, g, stream);
-        default: return fail(ICPX_ERR_INVALID, "no fused kernel for %d queries per lane x %d threads", g.qpt, g.threads);
+        default: break;
     }
+    return fail(ICPX_ERR_INVALID, "no fused kernel for %d queries per lane x %d threads", g.qpt, g.threads);
 }
 
 }  // namespace

@@ -1,7 +1,7 @@
 // icpx_prune.h — grid-pruned exact nearest-neighbour search for the fused pair kernel (batches).
 //
 // The brute-force search of icpx_filter.h looks at every (query, target) pair.  Here a pre-pass
-// (pair_perm_kernel, icpx_pair.h) bins every target cloud into a small uniform grid (<= 512 cells,
+// (pair_perm_kernel, icpx_pair.h) bins every target cloud into a small uniform grid (<= 4096 cells,
 // a handful of targets per cell) and sorts it by cell; the fused kernel stages the cloud into LDS in
 // that order together with the cell start table.  A query then only looks at the cells that can
 // hold a target within its current bound:
@@ -24,7 +24,7 @@
 
 namespace icpx {
 
-constexpr int kGridMaxCells = 512;
+constexpr int kGridMaxCells = 4096;
 constexpr int kGridTable = kGridMaxCells + 8;  // u16 entries reserved per cloud (cells + 1, padded)
 
 struct PairGrid {        // per target cloud, written by the pre-pass
@@ -47,13 +47,17 @@ ICPX_DEV int cell_of(double v, double lo, double scale, int G) {
     return static_cast<int>(x);
 }
 
-// cells per axis for a cloud of m points: about 6 targets per cell, at most kGridMaxCells cells
+#ifndef ICPX_GRID_DENSITY
+#define ICPX_GRID_DENSITY 1
+#endif
+// cells per axis for a cloud of m points: about ICPX_GRID_DENSITY targets per cell, at most
+// kGridMaxCells cells
 inline __host__ __device__ int grid_cells_per_axis(int dim, int m) {
     int G = 1;
     if (dim == 3) {
-        while (G < 8 && (G + 1) * (G + 1) * (G + 1) * 6 <= m) G++;
+        while (G < 16 && (G + 1) * (G + 1) * (G + 1) * ICPX_GRID_DENSITY <= m) G++;
     } else {
-        while (G < 22 && (G + 1) * (G + 1) * 6 <= m) G++;
+        while (G < 64 && (G + 1) * (G + 1) * ICPX_GRID_DENSITY <= m) G++;
     }
     return G;
 }
