@@ -6,7 +6,7 @@
 // that order together with the cell start table.  A query then only looks at the cells that can
 // hold a target within its current bound:
 //   seeded   bound = exact d2 to the previous neighbour (seed_bound)
-//   seedless bound = best of the query's own cell (then of the 3^D cells around it)
+//   seedless bound = best of the 3^D cells around the query (complete if that ball stays inside them)
 // and walks those cells one target per step, every lane on its own (the source cloud is handed
 // to the lanes in Morton order, so the lanes of a wave walk nearby cells and finish together).
 //
@@ -199,25 +199,29 @@ ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded
         return;
     }
     int c0[D], c1[D];
+    bool need = v;
     if (!seeded) {
         best = __builtin_inf();
         bslot = -1;
-        // the query's own cell, then the 3^D cells around it, give the first bound
-        int cq[D];
+        // first bound: the best of the 3^D cells around the query.  With about one target per cell
+        // the ball of that bound rarely leaves this box, and then the search is already complete
+        int b0[D], b1[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) cq[d] = cell_of(q[d], P.g.lo[d], P.g.scale[d], P.g.G);
-        grid_walk<D>(q, v, cq, cq, L, P, best, bslot);
-        if (__any(v && bslot < 0)) {
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                c0[d] = cq[d] > 0 ? cq[d] - 1 : 0;
-                c1[d] = cq[d] < P.g.G - 1 ? cq[d] + 1 : P.g.G - 1;
-            }
-            grid_walk<D>(q, v && bslot < 0, c0, c1, L, P, best, bslot);
+        for (int d = 0; d < D; d++) {
+            const int cq = cell_of(q[d], P.g.lo[d], P.g.scale[d], P.g.G);
+            b0[d] = cq > 0 ? cq - 1 : 0;
+            b1[d] = cq < P.g.G - 1 ? cq + 1 : P.g.G - 1;
         }
+        grid_walk<D>(q, v, b0, b1, L, P, best, bslot);
+        grid_range<D>(q, best, P.g, c0, c1);  // best = +inf (nothing found): every cell
+        bool inside = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) inside = inside && c0[d] >= b0[d] && c1[d] <= b1[d];
+        need = v && !inside;
+    } else {
+        grid_range<D>(q, best, P.g, c0, c1);
     }
-    grid_range<D>(q, best, P.g, c0, c1);  // best = +inf (nothing found yet): every cell
-    grid_walk<D>(q, v, c0, c1, L, P, best, bslot);
+    if (__any(need)) grid_walk<D>(q, need, c0, c1, L, P, best, bslot);
 }
 
 // ---- pre-pass helpers: Morton order of the source cloud -----------------------------------------
