@@ -641,9 +641,7 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
         ICPX_TRY(ws.xbest.reserve(sizeof(double) * (n_total > 0 ? n_total : 1)));
         ICPX_TRY(ws.grids.reserve(sizeof(PairGrid) * n_pairs));
         ICPX_TRY(ws.cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
-        const int npad = next_pow2(static_cast<int>(n_max > m_max ? n_max : m_max));
-        const size_t perm_lds = static_cast<size_t>(npad) * 12 + 512;
-        if (perm_lds > kMaxLds) return fail(ICPX_ERR_UNSUPPORTED, "permutation pre-pass: cloud too large");
+        const size_t perm_lds = 512 + 8 * static_cast<size_t>(kGridMaxCells + 4);
         auto pk = dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
         {
             static std::mutex mu;
@@ -655,9 +653,10 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
                 attr_set[dev * 4 + dim] = true;
             }
         }
-        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs), 2), dim3(npad >= 2048 ? 512 : 256), perm_lds, stream,
+        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs), 2), dim3((n_max > m_max ? n_max : m_max) >= 2048 ? 512 : 256),
+                           perm_lds, stream,
                            d_src, ws.soff.as<int64_t>(), d_dst, ws.doff.as<int64_t>(), ws.sperm.as<uint16_t>(),
-                           ws.tperm.as<uint16_t>(), ws.grids.as<PairGrid>(), ws.cstart.as<uint16_t>(), npad);
+                           ws.tperm.as<uint16_t>(), ws.grids.as<PairGrid>(), ws.cstart.as<uint16_t>(), 0);
         ICPX_HIP(hipGetLastError());
         pb.sperm = ws.sperm.as<uint16_t>();
         pb.tperm = ws.tperm.as<uint16_t>();

@@ -273,7 +273,7 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
 // Pre-pass of the pruned search, one workgroup per cloud of a batch.  grid (n_pairs, 2):
 //   y = 0  source cloud -> sperm: Morton order (the lanes of a wave then search nearby queries)
 //   y = 1  target cloud -> its grid (PairGrid), tperm: order by cell, cstart: cell start table
-// Dynamic LDS: npad_cap * 12 + 512 bytes.  The source order only affects speed; the target
+// Dynamic LDS: 512 + 8 * (kGridMaxCells + 4) bytes.  The source order only affects speed; the target
 // order, table and grid parameters are what the search's exactness argument rests on.
 template <int D>
 __global__ void __launch_bounds__(512)
@@ -300,11 +300,10 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
     }
     const double* __restrict__ pts = (is_t ? dst : src) + o0 * D;
     uint16_t* __restrict__ out = (is_t ? tperm : sperm) + o0;
-    int npad = 2;
-    while (npad < cnt) npad <<= 1;
-    uint64_t* key = reinterpret_cast<uint64_t*>(lds_raw);
-    uint32_t* val = reinterpret_cast<uint32_t*>(key + npad_cap);
-    double* red = reinterpret_cast<double*>(val + npad_cap);
+    // LDS: 64 doubles of reduction scratch, then the counting sort's histogram and cursors
+    double* red = lds_raw;
+    int* hist = reinterpret_cast<int*>(red + 64);
+    int* cursor = hist + kGridMaxCells + 4;
     double lo[D], hi[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
@@ -367,40 +366,64 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
         g.bad = any_bad ? 1 : 0;
         grids[blockIdx.x] = g;
     }
-    for (int i = tid; i < npad; i += T) {
-        uint64_t code = ~0ULL;
-        if (i < cnt) {
-            uint32_t c = 0;
-            if (is_t) {
-                // cell id, x fastest — the function the search evaluates for the queries
-                for (int d = D - 1; d >= 0; d--)
-                    c = c * G + static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G));
-            } else {
+    // counting sort by bucket: the cell id for targets; for sources a Morton code of 12 bits (their
+    // order only has to keep neighbours together).  Buckets <= kGridMaxCells.
+    const int SG = D == 3 ? 16 : 64;  // source buckets per axis
+    int nbuck = 1;
+    for (int d = 0; d < D; d++) nbuck *= is_t ? G : SG;
+    double sscale[D];
 #pragma unroll
-                for (int d = 0; d < D; d++) {
-                    uint32_t u = static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G));
-                    c |= (D == 3 ? spread3(u) : spread2(u)) << d;
-                }
+    for (int d = 0; d < D; d++) sscale[d] = is_t ? scale[d] : scale[d] * (static_cast<double>(SG) / G);
+    auto bucket = [&](int i) -> int {
+        uint32_t c = 0;
+        if (is_t) {
+            // cell id, x fastest — the function the search evaluates for the queries
+            for (int d = D - 1; d >= 0; d--)
+                c = c * G + static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G));
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                uint32_t u = static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], sscale[d], SG));
+                c |= (D == 3 ? spread3(u) : spread2(u)) << d;
             }
-            code = c;
         }
-        key[i] = code;
-        val[i] = static_cast<uint32_t>(i);
-    }
+        return static_cast<int>(c);
+    };
+    for (int c = tid; c <= nbuck; c += T) hist[c] = 0;
     __syncthreads();
-    bitonic_sort(key, val, npad, T);
-    for (int r = tid; r < cnt; r += T) out[r] = static_cast<uint16_t>(val[r]);
-    if (is_t) {
-        int ncell = G;
-        for (int d = 1; d < D; d++) ncell *= G;
-        for (int r = tid; r < cnt; r += T) {
-            const int cur = static_cast<int>(key[r]);
-            const int prev = r > 0 ? static_cast<int>(key[r - 1]) : -1;
-            for (int c = prev + 1; c <= cur; c++) table[c] = static_cast<uint16_t>(r);
-            if (r == cnt - 1)
-                for (int c = cur + 1; c <= ncell; c++) table[c] = static_cast<uint16_t>(cnt);
+    for (int i = tid; i < cnt; i += T) atomicAdd(&hist[bucket(i)], 1);
+    __syncthreads();
+    // exclusive scan of the bucket counts: per-thread chunk, wave scan, wave totals
+    const int chunk = (nbuck + T - 1) / T;
+    int local = 0;
+    for (int u = 0; u < chunk; u++) {
+        const int c = tid * chunk + u;
+        if (c < nbuck) local += hist[c];
+    }
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int up = __shfl_up(incl, o);
+        incl += lane >= o ? up : 0;
+    }
+    int* wtot = reinterpret_cast<int*>(red);  // the bounding-box values have been consumed above
+    __syncthreads();
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = incl - local;
+    for (int w = 0; w < wave; w++) base += wtot[w];
+    for (int u = 0; u < chunk; u++) {
+        const int c = tid * chunk + u;
+        if (c < nbuck) {
+            cursor[c] = base;
+            if (is_t) table[c] = static_cast<uint16_t>(base);
+            base += hist[c];
         }
     }
+    if (is_t && tid == 0) table[nbuck] = static_cast<uint16_t>(cnt);
+    __syncthreads();
+    // the order inside a bucket is whatever the atomics give: any order is a valid permutation
+    for (int i = tid; i < cnt; i += T) out[atomicAdd(&cursor[bucket(i)], 1)] = static_cast<uint16_t>(i);
 }
 
 // Correspondence step of the pruned mode.  The lanes take the queries in sorted order (lane tid,
