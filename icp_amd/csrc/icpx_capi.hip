@@ -177,7 +177,7 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     pl.threads = g.threads;
     pl.lds = g.lds;
     pl.cus = di->cus;
-    const bool prune = g.prune && pb.sperm && pb.tperm && pb.xbest && pb.seeds && pb.grids && pb.cstart;
+    const bool prune = g.prune && pb.tperm && pb.seeds && pb.grids && pb.cstart;
     if (g.prune && !prune) return fail(ICPX_ERR_INVALID, "pruned launch without its permutation buffers");
     if (pb.dim == 2) return prune ? launch_pairs_d2_prune(pb, n_pairs, pl, stream) : launch_pairs_d2_plain(pb, n_pairs, pl, stream);
     return prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream);
@@ -193,7 +193,7 @@ icpx_criteria no_criteria() {
 struct Workspace {
     std::mutex mu;
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
-    DevBuf sperm, tperm, xbest, grids, cstart;  // pruned search of the batch entry point
+    DevBuf tperm, grids, cstart;  // grid-pruned search of the batch entry point
     GridIndex* grid = nullptr;  // grow-only uniform-grid index of the stand-alone queries
 };
 Workspace& workspace(int device) {
@@ -635,32 +635,17 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
         pb.seeds = ws.seeds.as<int32_t>();
     }
     if (geom.prune) {
-        // Morton orders of all clouds (one pre-pass launch), exchange buffer of the search lanes
-        ICPX_TRY(ws.sperm.reserve(sizeof(uint16_t) * (n_total > 0 ? n_total : 1)));
+        // grid, cell order and cell table of every target cloud (one pre-pass launch)
         ICPX_TRY(ws.tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
-        ICPX_TRY(ws.xbest.reserve(sizeof(double) * (n_total > 0 ? n_total : 1)));
         ICPX_TRY(ws.grids.reserve(sizeof(PairGrid) * n_pairs));
         ICPX_TRY(ws.cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
         const size_t perm_lds = 512 + 8 * static_cast<size_t>(kGridMaxCells + 4);
         auto pk = dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
-        {
-            static std::mutex mu;
-            static std::unordered_map<int, bool> attr_set;  // per device and dimension
-            std::lock_guard<std::mutex> lk2(mu);
-            if (!attr_set[dev * 4 + dim]) {
-                ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             static_cast<int>(kMaxLds)));
-                attr_set[dev * 4 + dim] = true;
-            }
-        }
-        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs), 2), dim3((n_max > m_max ? n_max : m_max) >= 2048 ? 512 : 256),
-                           perm_lds, stream,
-                           d_src, ws.soff.as<int64_t>(), d_dst, ws.doff.as<int64_t>(), ws.sperm.as<uint16_t>(),
-                           ws.tperm.as<uint16_t>(), ws.grids.as<PairGrid>(), ws.cstart.as<uint16_t>(), 0);
+        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs)), dim3(m_max >= 2048 ? 512 : 256), perm_lds, stream,
+                           d_dst, ws.doff.as<int64_t>(), ws.tperm.as<uint16_t>(), ws.grids.as<PairGrid>(),
+                           ws.cstart.as<uint16_t>());
         ICPX_HIP(hipGetLastError());
-        pb.sperm = ws.sperm.as<uint16_t>();
         pb.tperm = ws.tperm.as<uint16_t>();
-        pb.xbest = ws.xbest.as<double>();
         pb.grids = ws.grids.as<PairGrid>();
         pb.cstart = ws.cstart.as<uint16_t>();
     }

@@ -71,12 +71,9 @@ struct PairBatch {
     // packed-f32 candidate filter in front of the exact f64 search (nn_filtered below)
     int32_t use_filter;        // the launch reserved the f32 target copy in LDS
     int32_t* seeds;            // n_total: previous nearest neighbour by point, carried between launches / tasks; may be nullptr
-    // pruned search (icpx_prune.h): Morton orders of the clouds (pair_perm_kernel) and the exchange
-    // buffer between the lanes that search (sorted order) and the lanes that own the points; with
-    // these set, `seeds` holds LDS slots (sorted order) instead of cloud indices.  All null = off
-    const uint16_t* sperm;     // n_total: source point at sorted position r of its pair
+    // grid-pruned search (icpx_prune.h; PRUNE kernels): per target cloud its order by grid cell
+    // (pair_perm_kernel); `seeds` then holds LDS slots (that order) instead of cloud indices
     const uint16_t* tperm;     // m_total: target at LDS slot j of its pair
-    double* xbest;             // n_total: d2 of the neighbour, by point
     const PairGrid* grids;     // n_pairs: grid of every target cloud
     const uint16_t* cstart;    // n_pairs x kGridTable: cell start tables
 };
@@ -270,36 +267,30 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
     __syncthreads();  // hist may be reused by the caller
 }
 
-// Pre-pass of the pruned search, one workgroup per cloud of a batch.  grid (n_pairs, 2):
-//   y = 0  source cloud -> sperm: Morton order (the lanes of a wave then search nearby queries)
-//   y = 1  target cloud -> its grid (PairGrid), tperm: order by cell, cstart: cell start table
-// Dynamic LDS: 512 + 8 * (kGridMaxCells + 4) bytes.  The source order only affects speed; the target
-// order, table and grid parameters are what the search's exactness argument rests on.
+// Pre-pass of the pruned search, one workgroup per target cloud of a batch: its grid (PairGrid),
+// tperm (order by cell, a counting sort) and cstart (cell start table).  Dynamic LDS: 512 + 8 *
+// (kGridMaxCells + 4) bytes.  Target order, table and grid parameters are what the search's
+// exactness argument rests on (icpx_prune.h).
 template <int D>
 __global__ void __launch_bounds__(512)
-pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src_off, const double* __restrict__ dst,
-                 const int64_t* __restrict__ dst_off, uint16_t* __restrict__ sperm, uint16_t* __restrict__ tperm,
-                 PairGrid* __restrict__ grids, uint16_t* __restrict__ cstart, int npad_cap) {
+pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst_off, uint16_t* __restrict__ tperm,
+                 PairGrid* __restrict__ grids, uint16_t* __restrict__ cstart) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    const bool is_t = blockIdx.y == 1;
-    const int64_t* off = is_t ? dst_off : src_off;
-    const int64_t o0 = off[blockIdx.x];
-    const int cnt = static_cast<int>(off[blockIdx.x + 1] - o0);
+    const int64_t o0 = dst_off[blockIdx.x];
+    const int cnt = static_cast<int>(dst_off[blockIdx.x + 1] - o0);
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
     uint16_t* __restrict__ table = cstart + static_cast<int64_t>(blockIdx.x) * kGridTable;
     if (cnt <= 0) {
-        if (is_t) {
-            if (tid == 0) {
-                PairGrid g{};
-                g.G = 1;
-                grids[blockIdx.x] = g;
-            }
-            for (int c = tid; c < kGridTable; c += T) table[c] = 0;
+        if (tid == 0) {
+            PairGrid g{};
+            g.G = 1;
+            grids[blockIdx.x] = g;
         }
+        for (int c = tid; c < kGridTable; c += T) table[c] = 0;
         return;
     }
-    const double* __restrict__ pts = (is_t ? dst : src) + o0 * D;
-    uint16_t* __restrict__ out = (is_t ? tperm : sperm) + o0;
+    const double* __restrict__ pts = dst + o0 * D;
+    uint16_t* __restrict__ out = tperm + o0;
     // LDS: 64 doubles of reduction scratch, then the counting sort's histogram and cursors
     double* red = lds_raw;
     int* hist = reinterpret_cast<int*>(red + 64);
@@ -337,7 +328,7 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
     const bool wave_bad = __any(bad);
     if (lane == 0) red[wave * 8 + 3] = wave_bad ? 1.0 : 0.0;
     __syncthreads();
-    const int G = is_t ? grid_cells_per_axis(D, cnt) : (D == 3 ? 1024 : 65536);
+    const int G = grid_cells_per_axis(D, cnt);
     double scale[D];
     bool any_bad = false;
     for (int w = 0; w < W; w++) any_bad = any_bad || red[w * 8 + 3] != 0.0;
@@ -356,7 +347,7 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
         scale[d] = h > l ? static_cast<double>(G) / (h - l) : 0.0;
         if (!(scale[d] < 1e300)) scale[d] = 0.0;
     }
-    if (is_t && tid == 0) {
+    if (tid == 0) {
         PairGrid g{};
         for (int d = 0; d < D; d++) {
             g.lo[d] = lo[d];
@@ -366,39 +357,24 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
         g.bad = any_bad ? 1 : 0;
         grids[blockIdx.x] = g;
     }
-    // counting sort by bucket: the cell id for targets; for sources a Morton code of 12 bits (their
-    // order only has to keep neighbours together).  Buckets <= kGridMaxCells.
-    const int SG = D == 3 ? 16 : 64;  // source buckets per axis
-    int nbuck = 1;
-    for (int d = 0; d < D; d++) nbuck *= is_t ? G : SG;
-    double sscale[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) sscale[d] = is_t ? scale[d] : scale[d] * (static_cast<double>(SG) / G);
-    auto bucket = [&](int i) -> int {
-        uint32_t c = 0;
-        if (is_t) {
-            // cell id, x fastest — the function the search evaluates for the queries
-            for (int d = D - 1; d >= 0; d--)
-                c = c * G + static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G));
-        } else {
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                uint32_t u = static_cast<uint32_t>(cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], sscale[d], SG));
-                c |= (D == 3 ? spread3(u) : spread2(u)) << d;
-            }
-        }
-        return static_cast<int>(c);
+    int ncell = 1;
+    for (int d = 0; d < D; d++) ncell *= G;
+    // cell id, x fastest — the function the search evaluates for the queries
+    auto cell_id = [&](int i) -> int {
+        int c = 0;
+        for (int d = D - 1; d >= 0; d--) c = c * G + cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G);
+        return c;
     };
-    for (int c = tid; c <= nbuck; c += T) hist[c] = 0;
+    for (int c = tid; c <= ncell; c += T) hist[c] = 0;
     __syncthreads();
-    for (int i = tid; i < cnt; i += T) atomicAdd(&hist[bucket(i)], 1);
+    for (int i = tid; i < cnt; i += T) atomicAdd(&hist[cell_id(i)], 1);
     __syncthreads();
-    // exclusive scan of the bucket counts: per-thread chunk, wave scan, wave totals
-    const int chunk = (nbuck + T - 1) / T;
+    // exclusive scan of the cell counts: per-thread chunk, wave scan, wave totals
+    const int chunk = (ncell + T - 1) / T;
     int local = 0;
     for (int u = 0; u < chunk; u++) {
         const int c = tid * chunk + u;
-        if (c < nbuck) local += hist[c];
+        if (c < ncell) local += hist[c];
     }
     int incl = local;
 #pragma unroll
@@ -407,95 +383,43 @@ pair_perm_kernel(const double* __restrict__ src, const int64_t* __restrict__ src
         incl += lane >= o ? up : 0;
     }
     int* wtot = reinterpret_cast<int*>(red);  // the bounding-box values have been consumed above
-    __syncthreads();
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     int base = incl - local;
     for (int w = 0; w < wave; w++) base += wtot[w];
     for (int u = 0; u < chunk; u++) {
         const int c = tid * chunk + u;
-        if (c < nbuck) {
+        if (c < ncell) {
             cursor[c] = base;
-            if (is_t) table[c] = static_cast<uint16_t>(base);
+            table[c] = static_cast<uint16_t>(base);
             base += hist[c];
         }
     }
-    if (is_t && tid == 0) table[nbuck] = static_cast<uint16_t>(cnt);
+    if (tid == 0) table[ncell] = static_cast<uint16_t>(cnt);
     __syncthreads();
-    // the order inside a bucket is whatever the atomics give: any order is a valid permutation
-    for (int i = tid; i < cnt; i += T) out[atomicAdd(&cursor[bucket(i)], 1)] = static_cast<uint16_t>(i);
+    // the order inside a cell is whatever the atomics give: any order is a valid permutation
+    for (int i = tid; i < cnt; i += T) out[atomicAdd(&cursor[cell_id(i)], 1)] = static_cast<uint16_t>(i);
 }
 
-// Correspondence step of the pruned mode.  The lanes take the queries in sorted order (lane tid,
-// slot k <-> sorted position tid + k*T, source point sp[k]), search, and hand (d2, slot) back to
-// the lanes that own the points through pb.xbest / pb.seeds; `sslot` carries the seeds between
-// iterations.  Workgroup-wide.
+// Correspondence step of the pruned mode: every lane searches its own QPT queries, one slot at a
+// time.  pair[k]: in = seed slot (seeded), out = LDS slot of the nearest target; best[k] = its d2.
+// (Handing the queries to the lanes in Morton order was tried: the walk is no faster with coherent
+// waves, and the exchange of queries and results through memory costs more than it saves.)
 template <int D, int QPT>
-ICPX_DEV void pruned_search(const PairBatch& pb, const double* __restrict__ src, const int64_t s0,
-                            const Xf<D>& X, const int (&sp)[QPT], int (&sslot)[QPT], const bool (&valid)[QPT],
-                            const bool seeded, const LdsView<D>& L, const GridView& P,
-                            const int m, double (&best)[QPT], int (&pair)[QPT]) {
-    const int T = blockDim.x, tid = threadIdx.x;
-#ifdef ICPX_STATS
-    const uint64_t ts0 = wall_clock64();
-    uint64_t st_slot = 0;
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // pb.cur of the step before (a barrier lies between)
-    XfRows<D> xr = xf_rows<D>(X);
-    // all queries first (their gathers overlap), then one slot at a time
-    double q[QPT][D];
+ICPX_DEV void pruned_search(const double (&q)[QPT][D], const bool (&valid)[QPT], const bool seeded,
+                            const LdsView<D>& L, const GridView& P, const int m, double (&best)[QPT],
+                            int (&pair)[QPT]) {
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
-        double pnt[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            double v = 0.0;
-            if (valid[k]) v = D == 2 ? src[static_cast<int64_t>(sp[k]) * D + d] : pb.cur[(s0 + sp[k]) * D + d];
-            pnt[d] = v;
-        }
-        if (D == 2) {
-            xf_apply<D>(xr, pnt, q[k]);  // a_current = transform * a (trimmed.cpp:49)
-        } else {
-#pragma unroll
-            for (int d = 0; d < D; d++) q[k][d] = pnt[d];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        const double (&qq)[D] = q[k];
         double b1[1] = {0.0};
-        int s1[1] = {sslot[k]};
+        int s1[1] = {pair[k]};
         if (seeded) {
-            const double (&q1)[1][D] = reinterpret_cast<const double (&)[1][D]>(qq);
+            const double (&q1)[1][D] = reinterpret_cast<const double (&)[1][D]>(q[k]);
             seed_bound<D, 1>(q1, L, m, b1, s1);
         }
-#ifdef ICPX_STATS
-        const uint64_t tp0 = wall_clock64();
-#endif
-        nn_grid_slot<D>(qq, valid[k], seeded, L, P, b1[0], s1[0]);
-#ifdef ICPX_STATS
-        st_slot += wall_clock64() - tp0;
-#endif
-        sslot[k] = s1[0];
-        if (valid[k]) {
-            pb.seeds[s0 + sp[k]] = s1[0];
-            pb.xbest[s0 + sp[k]] = b1[0];
-        }
-    }
-#ifdef ICPX_STATS
-    if ((threadIdx.x >> 6) == 0) {  // wave 0 of every workgroup
-        ICPX_STAT(13, st_slot);
-        ICPX_STAT(14, wall_clock64() - ts0);
-        ICPX_STAT(15, 1);
-    }
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        pair[k] = valid[k] ? pb.seeds[s0 + tid + k * T] : 0;
-        best[k] = valid[k] ? pb.xbest[s0 + tid + k * T] : 0.0;
+        nn_grid_slot<D>(q[k], valid[k], seeded, L, P, b1[0], s1[0]);
+        best[k] = valid[k] ? b1[0] : 0.0;
+        pair[k] = valid[k] ? s1[0] : 0;
     }
 }
 
@@ -552,21 +476,11 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         for (int d = 0; d < D; d++) {
             double v = 0.0;
             if (valid[k]) {
-                if (D == 3 && !do_setup) v = prune ? 0.0 : pb.cur[(s0 + i) * D + d];
+                if (D == 3 && !do_setup) v = pb.cur[(s0 + i) * D + d];
                 else v = src[static_cast<int64_t>(i) * D + d];
             }
             a[k][d] = v;
-            // pruned 3D: the running cloud lives in pb.cur only (the search lanes gather from it)
-            if (D == 3 && prune && do_setup && valid[k]) pb.cur[(s0 + i) * D + d] = v;
         }
-    }
-    if (D == 3 && prune) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-
-    int sp[QPT], sslot[QPT];  // pruned mode: source point / seed slot of sorted position tid + k*T
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        sp[k] = (prune && valid[k]) ? static_cast<int>(pb.sperm[s0 + tid + k * T]) : 0;
-        sslot[k] = 0;
     }
 
     // ---- state ----
@@ -594,10 +508,6 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     if (filter && !do_setup && pb.seeds && !empty && (D == 2 || st->iteration_count > 0)) {
 #pragma unroll
         for (int k = 0; k < QPT; k++) pair[k] = valid[k] ? pb.seeds[s0 + tid + k * T] : 0;
-        if (prune) {
-#pragma unroll
-            for (int k = 0; k < QPT; k++) sslot[k] = valid[k] ? pb.seeds[s0 + sp[k]] : 0;
-        }
         have_seed = true;
     }
 
@@ -625,7 +535,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            if (prune) pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, false, L, P, m, best, pair);
+            if (prune) pruned_search<D, QPT>(q, valid, false, L, P, m, best, pair);
             else if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
             else nn_lds<D, QPT>(q, L, m4, best, pair);
             have_seed = filter;
@@ -709,7 +619,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
                     if (prune) {
-                        pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, m, best, pair);
+                        pruned_search<D, QPT>(cur, valid, have_seed, L, P, m, best, pair);
                     } else if (have_seed) {
                         seed_bound<D, QPT>(cur, L, m, best, pair);
                         nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
@@ -747,18 +657,12 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             } else {
                 // 3D: nearest_neighbor(c), vanilla_3d.cpp:30-45
                 double best[QPT];
-                if (!prune) {
 #pragma unroll
-                    for (int k = 0; k < QPT; k++)
+                for (int k = 0; k < QPT; k++)
 #pragma unroll
-                        for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
-                }
+                    for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 if (prune) {
-                    pruned_search<D, QPT>(pb, src, s0, X, sp, sslot, valid, have_seed, L, P, m, best, pair);
-#pragma unroll
-                    for (int k = 0; k < QPT; k++)
-#pragma unroll
-                        for (int d = 0; d < D; d++) cur[k][d] = valid[k] ? pb.cur[(s0 + tid + k * T) * D + d] : 0.0;
+                    pruned_search<D, QPT>(cur, valid, have_seed, L, P, m, best, pair);
                 } else if (have_seed) {
                     seed_bound<D, QPT>(cur, L, m, best, pair);
                     nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
@@ -837,18 +741,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int e = 0; e < XN; e++) S.m[e] = L.bc[16 + e];
                 XfRows<D> sr = xf_rows<D>(S);
 #pragma unroll
-                for (int k = 0; k < QPT; k++) {
-                    if (prune) {
-                        double nc[D];
-                        xf_apply<D>(sr, cur[k], nc);
-                        if (valid[k])
-#pragma unroll
-                            for (int d = 0; d < D; d++) pb.cur[(s0 + tid + k * T) * D + d] = nc[d];
-                    } else {
-                        xf_apply<D>(sr, cur[k], a[k]);
-                    }
-                }
-                if (prune) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                for (int k = 0; k < QPT; k++) xf_apply<D>(sr, cur[k], a[k]);
             }
             if (D == 2 && METHOD == ICPX_TRIMMED) state_cost = __builtin_sqrt(s1[2 * D] / static_cast<double>(n));
             __syncthreads();
@@ -866,7 +759,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         for (int k = 0; k < QPT; k++)
             if (valid[k]) pb.seeds[s0 + tid + k * T] = pair[k];
     }
-    if (D == 3 && pb.cur && !prune) {
+    if (D == 3 && pb.cur) {
 #pragma unroll
         for (int k = 0; k < QPT; k++)
             if (valid[k])

@@ -7,8 +7,7 @@
 // hold a target within its current bound:
 //   seeded   bound = exact d2 to the previous neighbour (seed_bound)
 //   seedless bound = best of the 3^D cells around the query (complete if that ball stays inside them)
-// and walks those cells one target per step, every lane on its own (the source cloud is handed
-// to the lanes in Morton order, so the lanes of a wave walk nearby cells and finish together).
+// and walks those cells two targets per step, every lane on its own.
 //
 // Exactness.  cell_of() is a monotone function of the coordinate, evaluated by the same code for
 // targets (pre-pass) and queries (here).  A target with exact d2 <= bound differs from the query
@@ -222,24 +221,6 @@ ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded
         grid_range<D>(q, best, P.g, c0, c1);
     }
     if (__any(need)) grid_walk<D>(q, need, c0, c1, L, P, best, bslot);
-}
-
-// ---- pre-pass helpers: Morton order of the source cloud -----------------------------------------
-ICPX_DEV uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
-    v &= 0x3ff;
-    v = (v | (v << 16)) & 0x030000ff;
-    v = (v | (v << 8)) & 0x0300f00f;
-    v = (v | (v << 4)) & 0x030c30c3;
-    v = (v | (v << 2)) & 0x09249249;
-    return v;
-}
-ICPX_DEV uint32_t spread2(uint32_t v) {  // 16 bits -> every second bit
-    v &= 0xffff;
-    v = (v | (v << 8)) & 0x00ff00ff;
-    v = (v | (v << 4)) & 0x0f0f0f0f;
-    v = (v | (v << 2)) & 0x33333333;
-    v = (v | (v << 1)) & 0x55555555;
-    return v;
 }
 
 }  // namespace icpx
