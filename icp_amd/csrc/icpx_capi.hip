@@ -183,6 +183,20 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     return prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream);
 }
 
+// pre-pass of the grid-pruned search (icpx_prune.h): grid, cell order and cell table of every target cloud
+int enqueue_prepass(int dim, int64_t n_pairs, int64_t m_max, int64_t m_total, const double* d_dst, const int64_t* d_doff,
+                    DevBuf& tperm, DevBuf& grids, DevBuf& cstart, hipStream_t stream) {
+    ICPX_TRY(tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
+    ICPX_TRY(grids.reserve(sizeof(PairGrid) * n_pairs));
+    ICPX_TRY(cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
+    const size_t perm_lds = 512 + 8 * static_cast<size_t>(kGridMaxCells + 4);
+    auto pk = dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
+    hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs)), dim3(m_max >= 2048 ? 512 : 256), perm_lds, stream, d_dst,
+                       d_doff, tperm.as<uint16_t>(), grids.as<PairGrid>(), cstart.as<uint16_t>());
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
 icpx_criteria no_criteria() {
     icpx_criteria c;
     std::memset(&c, 0, sizeof(c));
@@ -220,6 +234,7 @@ struct icpx_ctx {
     bool large = false;
     PairGeom geom{};
     DevBuf src, dst, cur, off, guess, m_point, m_pair, m_cost, pair_tmp, seeds, state, out;
+    DevBuf tperm, grids, cstart;  // grid-pruned search (geom.prune)
     LargeIcp* lg = nullptr;
 };
 
@@ -254,6 +269,9 @@ int upload_pair(icpx_ctx* h, const double* source, int64_t n, const double* targ
     ICPX_HIP(hipStreamSynchronize(h->stream));
     h->n = n;
     h->m = m;
+    if (h->geom.prune)
+        ICPX_TRY(enqueue_prepass(D, 1, m, m, h->dst.as<double>(), h->off.as<int64_t>() + 2, h->tperm, h->grids, h->cstart,
+                                 h->stream));
     return ICPX_OK;
 }
 
@@ -278,6 +296,11 @@ void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
     pb.overlap_rate = h->prm.overlap_rate;
     pb.max_distance = h->prm.max_distance;
     pb.clock_to_s = di.clock_to_s;
+    if (h->geom.prune) {
+        pb.tperm = h->tperm.as<uint16_t>();
+        pb.grids = h->grids.as<PairGrid>();
+        pb.cstart = h->cstart.as<uint16_t>();
+    }
 }
 
 int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* target, int64_t m,
@@ -292,7 +315,12 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     // Development override: ICPX_FUSED_SINGLE_MAX = largest n*m that stays fused
     double single_max = kFusedSingleMaxWork;
     if (const char* e = std::getenv("ICPX_FUSED_SINGLE_MAX")) single_max = std::atof(e);
-    bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom) &&
+    // A single scan-sized pair iterates faster with the brute-force filter (scan1, 22 iterations: 1.6 ms
+    // against 2.1 ms through the grid), so handles keep it; ICPX_PRUNE_HANDLES=1 sends them through the
+    // grid-pruned kernels of the batch path (tests do, to run the whole handle suite over those kernels)
+    const char* ph = std::getenv("ICPX_PRUNE_HANDLES");
+    const bool prune_handles = ph && ph[0] == '1';
+    bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles) &&
                  static_cast<double>(n) * static_cast<double>(m) <= single_max &&
                  h->method != ICPX_FEATURE_AWARE &&  // feature_aware and the opt-in corrected modes run on
                  h->prm.flags == 0;                  // the multi-kernel path only
@@ -300,7 +328,7 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     h->large = !fused;
     if (h->large && (n == 0 || m == 0)) {
         // empty clouds carry no work: run them through the fused kernel's no-op path
-        h->large = !fused_fits(h->dim, h->method, n, m, &h->geom);
+        h->large = !fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles);
     }
     return ICPX_OK;
 }
@@ -371,7 +399,7 @@ int icpx_destroy(icpx_handle h) {
     (void)g.enter(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->src, &h->dst, &h->cur, &h->off, &h->guess, &h->m_point, &h->m_pair,
-                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out})
+                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart})
         b->release();
     if (h->lg) large_destroy(h->lg);
     delete h;
@@ -635,16 +663,8 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
         pb.seeds = ws.seeds.as<int32_t>();
     }
     if (geom.prune) {
-        // grid, cell order and cell table of every target cloud (one pre-pass launch)
-        ICPX_TRY(ws.tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
-        ICPX_TRY(ws.grids.reserve(sizeof(PairGrid) * n_pairs));
-        ICPX_TRY(ws.cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
-        const size_t perm_lds = 512 + 8 * static_cast<size_t>(kGridMaxCells + 4);
-        auto pk = dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
-        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs)), dim3(m_max >= 2048 ? 512 : 256), perm_lds, stream,
-                           d_dst, ws.doff.as<int64_t>(), ws.tperm.as<uint16_t>(), ws.grids.as<PairGrid>(),
-                           ws.cstart.as<uint16_t>());
-        ICPX_HIP(hipGetLastError());
+        ICPX_TRY(enqueue_prepass(dim, n_pairs, m_max, m_total, d_dst, ws.doff.as<int64_t>(), ws.tperm, ws.grids, ws.cstart,
+                                 stream));
         pb.tperm = ws.tperm.as<uint16_t>();
         pb.grids = ws.grids.as<PairGrid>();
         pb.cstart = ws.cstart.as<uint16_t>();

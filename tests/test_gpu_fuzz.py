@@ -12,9 +12,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [3, 11])
-def test_fuzz_fused_kernels_against_oracle(seed):
+@pytest.mark.parametrize("seed,prune", [(3, "0"), (11, "0"), (3, "1"), (17, "1")])
+def test_fuzz_fused_kernels_against_oracle(seed, prune):
+    """prune = "1": handles and batches go through the grid-pruned kernels (icpx_prune.h);
+    "0": through the brute-force f32 filter + exact refinement."""
+    env = dict(os.environ, ICPX_PRUNE=prune, ICPX_PRUNE_HANDLES=prune)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_filter.py"), str(seed), "60"],
-                         capture_output=True, text=True, timeout=280)
+                         capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "0 mismatches" in out.stdout

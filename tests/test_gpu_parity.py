@@ -117,9 +117,11 @@ def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen):
 # whole converge() runs
 # ------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("prune_handles", ["0", "1"])
 @pytest.mark.parametrize("method", ["vanilla", "trimmed"])
 @pytest.mark.parametrize("k", [1, 2, 3])
-def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k):
+def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k, prune_handles, monkeypatch):
+    monkeypatch.setenv("ICPX_PRUNE_HANDLES", prune_handles)  # "1": handles through the grid-pruned kernels
     a, b = scans[k]
     d = driver(icp, icp.ICP2, method, BENCH_CRIT)
     r = d.converge(a, b)
@@ -170,8 +172,10 @@ def test_queen_large_path(icp, ob, queen, traces, method, nn):
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
 
 
+@pytest.mark.parametrize("prune_handles", ["0", "1"])
 @pytest.mark.parametrize("dim,method", [(2, "vanilla"), (2, "trimmed"), (3, "vanilla"), (3, "trimmed")])
-def test_stepwise_begin_iterate_matches_oracle_every_iteration(icp, ob, scans, dim, method):
+def test_stepwise_begin_iterate_matches_oracle_every_iteration(icp, ob, scans, dim, method, prune_handles, monkeypatch):
+    monkeypatch.setenv("ICPX_PRUNE_HANDLES", prune_handles)  # "1": handles through the grid-pruned kernels
     if dim == 2:
         a, b = scans[3]
         cfg = None
@@ -377,7 +381,9 @@ def test_large_path_sum_layouts_agree(icp, ob, monkeypatch):
     assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
 
 
-def test_filtered_search_adversarial_inputs(icp, ob):
+@pytest.mark.parametrize("prune_handles", ["0", "1"])
+def test_filtered_search_adversarial_inputs(icp, ob, prune_handles, monkeypatch):
+    monkeypatch.setenv("ICPX_PRUNE_HANDLES", prune_handles)  # "1": the same inputs through the grid-pruned kernels
     """The f32 candidate filter of the fused kernel must never change a result: exact ties
     (lattices, duplicated targets), clouds far from the origin (the filter works about the target's
     bounding-box centre), tiny and huge scales (f32 underflow / the >= 1e18 fall-back to the plain
