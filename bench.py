@@ -131,6 +131,7 @@ def main():
         flops3 = float((it3 * (8.0 * N_3D * N_3D)).sum())
         achieved = flops3 / (k3 * 1e-3) / 1e12
         traffic = measured_traffic()
+        valu = measured_traffic("valu_instructions_per_launch")
         line = {
             "metric": "nn_correspondence_queries_per_s",
             "value": total_q / (elapsed / args.steps),
@@ -173,6 +174,10 @@ def main():
                 "launch_ms": k3,
                 "flops_per_launch": flops3,
                 "traffic": traffic,
+                # executed work: wave-level VALU instructions of the launch (PMC SQ_INSTS_VALU, profiles/) x 4 issue
+                # cycles over the cycles 1024 SIMDs have in the launch at 2.4 GHz — how busy the pruned kernel
+                # keeps the vector units (it is bound by the LDS round trips of its per-lane cell walks)
+                "valu_issue_frac": None if valu is None else valu * 4.0 / (1024 * 2.4e9 * k3 * 1e-3),
                 # the other roofline of the same launch: HBM bytes (PMC, profiles/) over its duration
                 "hbm": None if traffic is None else {"achieved": traffic / (k3 * 1e-3) / 1e9, "peak": 8000.0,
                                                      "unit": "GB/s", "frac": traffic / (k3 * 1e-3) / 1e9 / 8000.0},
@@ -188,8 +193,8 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC passes
+def measured_traffic(field="hbm_bytes_per_launch_raw"):
+    """HBM bytes (or another summarized counter) per launch of the dominant kernel from the newest committed PMC passes
     (profiles/*_counters.json, tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs of this same command).  PMC counters cannot be read from inside this process;
     None when absent."""
@@ -200,8 +205,8 @@ def measured_traffic():
             with open(path) as f:
                 k = json.load(f)["kernels"]
             for name, v in k.items():
-                if "pair_kernel<3, 0" in name and "hbm_bytes_per_launch_raw" in v:
-                    return v["hbm_bytes_per_launch_raw"]
+                if "pair_kernel<3, 0" in name and field in v:
+                    return v[field]
         except (OSError, KeyError, ValueError):
             continue
     return None
