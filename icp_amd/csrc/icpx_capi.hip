@@ -113,7 +113,7 @@ constexpr double kFusedSingleMaxWork = 1.1e6;  // measured crossover (n = m = 10
 struct PairGeom {
     int qpt, threads, tcap, scap;
     bool filter;  // f32 target copy reserved in LDS (nn_filtered)
-    bool prune;   // Morton-ordered clouds + target boxes (icpx_prune.h); batches only
+    bool prune;   // grid-pruned search (icpx_prune.h): targets ordered by cell, cell table in LDS
     size_t lds;
 };
 

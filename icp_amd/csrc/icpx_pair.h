@@ -3,9 +3,11 @@
 //
 // Per iteration, without leaving the kernel (reference: lib/icp/impl/{vanilla,trimmed,vanilla_3d,
 // trimmed_3d}.cpp iterate(); include/icp/driver.h:51-72,154-222):
-//   transform apply  ->  brute-force NN against the target cloud staged in LDS (SoA, broadcast
-//   reads; each lane owns up to QPT queries in registers)  ->  selection (2D trimmed: bitonic
-//   sort of (cost, point) keys in LDS; 3D trimmed: distance threshold)  ->  centroid and
+//   transform apply  ->  exact NN against the target cloud staged in LDS (SoA; each lane owns up
+//   to QPT queries in registers): f32 candidate filter + exact f64 refinement over all targets
+//   (icpx_filter.h), or — PRUNE kernels, batches — a walk of the cells of a per-pair grid that can
+//   hold a closer target (icpx_prune.h)  ->  selection (2D trimmed: radix select of the
+//   overlap_rate * n-th (cost, point) key; 3D trimmed: distance threshold)  ->  centroid and
 //   cross-covariance sums in the TREE64 order (wave butterfly, then one butterfly over the <= 64
 //   group sums)  ->  single-lane Jacobi SVD / Kabsch  ->  transform composition, cost,
 //   should_terminate.
