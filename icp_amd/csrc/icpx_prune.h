@@ -168,8 +168,11 @@ ICPX_DEV void grid_walk(const double (&q)[D], bool act, const int (&c0)[D], cons
 // cell range that holds every target within sqrt(bound) of q on each axis
 template <int D>
 ICPX_DEV void grid_range(const double (&q)[D], double bound, const PairGrid& g, int (&c0)[D], int (&c1)[D]) {
-    // R' >= sqrt(bound): the correctly rounded root is >= (1 - 2^-53) of the true one
-    const double R = __builtin_sqrt(bound) * (1.0 + 1.0 / 1125899906842624.0) + 1e-300;
+    // A target whose COMPUTED d2 is <= bound has fl(dx * dx) <= bound for dx = fl(t - q) on every axis
+    // (the sum only adds non-negative terms and rounding is monotone), hence |t - q| <= sqrt(bound) *
+    // (1 + 2^-51) + 2^-537 (the second term: squares that underflow).  R' covers that: the correctly
+    // rounded root is >= (1 - 2^-53) of the true one, times (1 + 2^-50), plus 1e-150
+    const double R = __builtin_sqrt(bound) * (1.0 + 1.0 / 1125899906842624.0) + 1e-150;
 #pragma unroll
     for (int d = 0; d < D; d++) {
         // q -/+ R' rounds by at most 2^-53 (|q| + R'): widen by 2^-51 of that
