@@ -432,9 +432,36 @@ ICPX_DEV bool should_terminate(const icpx_criteria& c, const PairState& s, doubl
 
 // 64-lane xor butterfly sum: every lane ends with the same value; the association order is the
 // one DESIGN.md calls TREE64 (v[l] + v[l^32], then ^16, ... ^1).
+// value of lane (l ^ DIST) for DIST in {8, 4, 2, 1}: DPP moves inside a row of 16 lanes (VALU, no LDS
+// round trip): row_ror:8; row_shl:4 into banks 0, 2 + row_shr:4 into banks 1, 3; quad_perm
+template <int DIST>
+ICPX_DEV double dpp_xor(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (DIST == 8) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
+    } else if (DIST == 4) {
+        int l2 = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false);   // lanes 0-3, 8-11 <- lane + 4
+        int h2 = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
+        lo = __builtin_amdgcn_update_dpp(l2, lo, 0x114, 0xf, 0xa, false);      // lanes 4-7, 12-15 <- lane - 4
+        hi = __builtin_amdgcn_update_dpp(h2, hi, 0x114, 0xf, 0xa, false);
+    } else if (DIST == 2) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false);        // quad_perm [2,3,0,1]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
 ICPX_DEV double wave_sum(double v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    v = v + __shfl_xor(v, 32, 64);
+    v = v + __shfl_xor(v, 16, 64);
+    v = v + dpp_xor<8>(v);
+    v = v + dpp_xor<4>(v);
+    v = v + dpp_xor<2>(v);
+    v = v + dpp_xor<1>(v);
     return v;
 }
 ICPX_DEV int wave_sum_int(int v) {
