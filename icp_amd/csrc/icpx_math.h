@@ -455,9 +455,31 @@ ICPX_DEV double dpp_xor(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// value of lane (l ^ 32) / (l ^ 16): gfx950's v_permlane32_swap / v_permlane16_swap of the value with
+// itself leave {lower half | even rows} in one result and {upper half | odd rows} in the other
+// (tools/micro/permlane_probe.hip); each lane picks the one that holds its partner
+template <int DIST>
+ICPX_DEV double swap_xor(double v) {
+    const unsigned lo = static_cast<unsigned>(__double2loint(v)), hi = static_cast<unsigned>(__double2hiint(v));
+    const bool upper = (threadIdx.x & DIST) != 0;
+    unsigned plo, phi;
+    if (DIST == 32) {
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        plo = upper ? a[0] : a[1];
+        phi = upper ? b[0] : b[1];
+    } else {
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        plo = upper ? a[0] : a[1];
+        phi = upper ? b[0] : b[1];
+    }
+    return __hiloint2double(static_cast<int>(phi), static_cast<int>(plo));
+}
+
 ICPX_DEV double wave_sum(double v) {
-    v = v + __shfl_xor(v, 32, 64);
-    v = v + __shfl_xor(v, 16, 64);
+    v = v + swap_xor<32>(v);
+    v = v + swap_xor<16>(v);
     v = v + dpp_xor<8>(v);
     v = v + dpp_xor<4>(v);
     v = v + dpp_xor<2>(v);
