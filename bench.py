@@ -43,6 +43,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--pairs-total", type=int, default=0,
+                    help="strong scaling: this many pairs in all (half 2D, half 3D; config 5 names 8192) split over the "
+                         "ranks; default 0 = weak scaling, 512 + 512 pairs per GPU")
+    ap.add_argument("--verify-pairs", type=int, default=2, help="pairs per kind checked against the oracle after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=512, help="pairs per dim timed on the CPU")
     args = ap.parse_args()
 
@@ -50,7 +54,7 @@ def main():
     import torch.distributed as dist
 
     import icp_amd
-    from icp_amd import synth
+    from icp_amd import shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -64,35 +68,26 @@ def main():
 
     icp_amd._lib.check(icp_amd._lib.load().icpx_init(local_rank))
 
-    # ---- this rank's shard of the batch (pair ids are global: rank r owns [r*512, (r+1)*512)) ----
-    ids = np.arange(rank * PAIRS_2D, (rank + 1) * PAIRS_2D)
-    s2, t2, off2, _ = synth.config5_pairs(ids, 2, N_2D)
-    ids3 = np.arange(rank * PAIRS_3D, (rank + 1) * PAIRS_3D)
-    s3, t3, off3, _ = synth.config5_pairs(ids3, 3, N_3D)
-    d_s2, d_t2 = torch.from_numpy(s2).to(dev), torch.from_numpy(t2).to(dev)
-    d_s3, d_t3 = torch.from_numpy(s3).to(dev), torch.from_numpy(t3).to(dev)
-    out2 = torch.zeros(PAIRS_2D * 18, dtype=torch.float64, device=dev)  # icpx_state = 144 B
-    out3 = torch.zeros(PAIRS_3D * 18, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world * (PAIRS_2D + PAIRS_3D) * 18, dtype=torch.float64, device=dev) if world > 1 else None
-    crit = icp_amd.make_criteria(max_iterations=MAX_ITER, transform_tol=TOL)
-    stream = torch.cuda.current_stream().cuda_stream
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    k3_ms = []
+    # ---- this rank's shard of the batch: icp_amd.shard decides who owns which pair ids ----
+    from icp_amd import workload
+    if args.pairs_total:
+        total2 = total3 = args.pairs_total // 2   # strong scaling: the whole config-5 batch over `world` ranks
+        scaling = "strong"
+    else:
+        total2, total3 = PAIRS_2D * world, PAIRS_3D * world   # weak scaling: a fixed shard per GPU
+        scaling = "weak"
+    sh = workload.Config5Shard(torch, rank, world, total2, total3, local_rank)
+    s2, t2, off2, s3, t3, off3 = sh.s2, sh.t2, sh.off2, sh.s3, sh.t3, sh.off3
+    k3_ms, k2_ms = [], []
 
     def step(timed_kernel=False):
-        icp_amd.converge_batch(2, "trimmed", d_s2, off2, d_t2, off2, crit, out_states=out2,
-                               device=local_rank, stream=stream)
-        if timed_kernel:
-            ev[0].record()
-        icp_amd.converge_batch(3, "vanilla", d_s3, off3, d_t3, off3, crit, out_states=out3,
-                               device=local_rank, stream=stream)
-        if timed_kernel:
-            ev[1].record()
+        sh.step(timed=timed_kernel)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, torch.cat([out2, out3]))
+            gathered = shard.gather_states(sh.out, total2 + total3, rank, world, counts=(total2, total3))
         if timed_kernel:
-            torch.cuda.synchronize()
-            k3_ms.append(ev[0].elapsed_time(ev[1]))
+            a, b = sh.launch_ms()
+            k3_ms.append(a)
+            k2_ms.append(b)
 
     def barrier():
         if world > 1:
@@ -113,21 +108,29 @@ def main():
         elapsed = float(tt.item())
 
     # ---- work accounting from the results (deterministic across steps) ----
-    st2 = out2.cpu().numpy().view(np.dtype([("cost", "f8"), ("it", "u8"), ("T", "f8", 16)]))
-    st3 = out3.cpu().numpy().view(np.dtype([("cost", "f8"), ("it", "u8"), ("T", "f8", 16)]))
+    st2, st3 = sh.states()
     it2, it3 = st2["it"].astype(np.int64), st3["it"].astype(np.int64)
     # NN steps: trimmed ICP2 matches once in setup (trimmed.cpp:31-36) and once per iterate;
     # vanilla ICP3 once per iterate (vanilla_3d.cpp:85)
     q2 = int(((it2 + 1) * N_2D).sum())
     q3 = int((it3 * N_3D).sum())
-    queries = torch.tensor([q2 + q3, PAIRS_2D + PAIRS_3D], dtype=torch.float64, device=dev)
+    queries = torch.tensor([q2 + q3, sh.p2 + sh.p3], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(queries, op=dist.ReduceOp.SUM)
     total_q, total_pairs = float(queries[0].item()), float(queries[1].item())
 
+    # ---- after the timed region: a sample of this shard's results against the CPU oracle (the checker) ----
+    verified = 0
+    if args.verify_pairs > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+        import bench_check
+        from oracle import binding as ob
+        verified = bench_check.verify_sample(ob, sh, args.verify_pairs)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         k3 = float(np.mean(k3_ms)) if k3_ms else float("nan")
+        k2 = float(np.mean(k2_ms)) if k2_ms else float("nan")
         flops3 = float((it3 * (8.0 * N_3D * N_3D)).sum())
         achieved = flops3 / (k3 * 1e-3) / 1e12
         traffic = measured_traffic()
@@ -141,16 +144,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "converged_pairs_per_s": total_pairs / (elapsed / args.steps),
+            "verified_pairs": verified,
+            "launch_ms": {"3d": k3, "2d": k2},
             "config": {
                 "workload": "BASELINE config 5 shard per GPU: 512 2D pairs (n=m=1024, trimmed ICP2, "
                             "overlap 0.9) + 512 3D pairs (n=m=4096, vanilla ICP3), ICPDriver "
                             "max_iterations=50, transform tolerance (1e-4, 1e-4); results gathered with RCCL",
-                "pairs_per_gpu": PAIRS_2D + PAIRS_3D,
+                "pairs_per_gpu": sh.p2 + sh.p3,
                 "mean_iterations_2d": float(it2.mean()),
                 "mean_iterations_3d": float(it3.mean()),
                 "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",

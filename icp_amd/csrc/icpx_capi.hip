@@ -18,6 +18,8 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <algorithm>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -25,6 +27,8 @@
 #include "icpx_large.h"
 #include "icpx_nn.h"
 #include "icpx_pair.h"
+
+struct icpx_ctx;
 
 namespace icpx {
 
@@ -43,6 +47,47 @@ int stats_read_d3_prune(unsigned long long*, int);
 std::string& last_error_ref() {
     static thread_local std::string s;
     return s;
+}
+
+namespace {
+// "ICPX_X" -> knob value; value == nullptr restores the built-in default
+bool set_knob(Knobs& k, const char* name, const char* value) {
+    const std::string n = name ? name : "";
+    const int iv = value ? std::atoi(value) : 0;
+    if (n == "ICPX_PRUNE") k.prune = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_FILTER") k.filter = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_SCHED") k.sched = value ? (value[0] == '1' ? 1 : 0) : -1;
+    else if (n == "ICPX_SCHED_STEPS") k.sched_steps = (value && iv >= 1 && iv <= 64) ? iv : 0;
+    else if (n == "ICPX_PRUNE_HANDLES") k.prune_handles = value ? (value[0] == '1') : 0;
+    else if (n == "ICPX_NO_GROUP_SUMS") k.no_group_sums = value ? 1 : 0;
+    else if (n == "ICPX_COOP") k.coop = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_FUSED_SINGLE_MAX") k.fused_single_max = value ? std::atof(value) : -1.0;
+    else if (n == "ICPX_GEOM") {
+        int q = 0, t = 0;
+        if (value && std::sscanf(value, "%d,%d", &q, &t) == 2) {
+            k.geom_qpt = q;
+            k.geom_threads = t;
+        } else {
+            k.geom_qpt = 0;
+            k.geom_threads = 0;
+        }
+    } else {
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
+Knobs& knobs() {
+    static Knobs k;
+    static const bool from_env = [] {
+        for (const char* n : {"ICPX_PRUNE", "ICPX_FILTER", "ICPX_SCHED", "ICPX_SCHED_STEPS", "ICPX_PRUNE_HANDLES",
+                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
+            if (const char* v = std::getenv(n)) set_knob(k, n, v);
+        return true;
+    }();
+    (void)from_env;
+    return k;
 }
 
 namespace {
@@ -131,10 +176,10 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
     }
     else if (n <= 2048) { if (dim == 2) { r.qpt = 8; r.threads = 256; } else { r.qpt = 4; r.threads = 512; } }
     else { r.qpt = 8; r.threads = 512; }
-    // development override: ICPX_GEOM="qpt,threads" (must cover n)
-    if (const char* e = std::getenv("ICPX_GEOM")) {
-        int q = 0, t = 0;
-        if (std::sscanf(e, "%d,%d", &q, &t) == 2 && static_cast<int64_t>(q) * t >= n) {
+    // development knob ICPX_GEOM="qpt,threads" (must cover n)
+    {
+        const int q = knobs().geom_qpt, t = knobs().geom_threads;
+        if (q > 0 && t > 0 && static_cast<int64_t>(q) * t >= n) {
             r.qpt = q;
             r.threads = t;
         }
@@ -144,15 +189,13 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
     // sort area: only the sorted matches of trimmed ICP2 (published through a handle) need it
     r.scap = (dim == 2 && method == ICPX_TRIMMED && want_matches) ? next_pow2(static_cast<int>(n)) : 0;
     // the packed-f32 candidate filter needs 4 more bytes of LDS per target coordinate; 2D vanilla
-    // searches once per begin and never uses it.  Development override: ICPX_FILTER=0
-    const char* fe = std::getenv("ICPX_FILTER");
-    r.filter = !(dim == 2 && method == ICPX_VANILLA) && !(fe && fe[0] == '0') &&
+    // searches once per begin and never uses it.  Development knob: ICPX_FILTER=0
+    r.filter = !(dim == 2 && method == ICPX_VANILLA) && knobs().filter != 0 &&
                pair_lds_bytes(dim, r.tcap, r.scap, true) <= kMaxLds;
     r.prune = false;
     if (allow_prune && !(dim == 2 && method == ICPX_VANILLA) && m >= 128 && m < 65536) {
-        // grid-pruned search (icpx_prune.h); development override: ICPX_PRUNE=0
-        const char* pe = std::getenv("ICPX_PRUNE");
-        if (!(pe && pe[0] == '0') && pair_lds_bytes(dim, r.tcap, r.scap, false, true) <= kMaxLds) {
+        // grid-pruned search (icpx_prune.h); development knob: ICPX_PRUNE=0
+        if (knobs().prune != 0 && pair_lds_bytes(dim, r.tcap, r.scap, false, true) <= kMaxLds) {
             r.prune = true;
             r.filter = false;  // no f32 copy in LDS
         }
@@ -203,19 +246,51 @@ icpx_criteria no_criteria() {
     return c;
 }
 
-// per-device grow-only workspace for the handle-free entry points
+// Grow-only workspace of the handle-free entry points, one per (device, stream): calls on different
+// streams of one device run concurrently (bench.py overlaps its 2D and its 3D batch this way); calls on
+// the same stream serialise on `mu`.
 struct Workspace {
     std::mutex mu;
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
     DevBuf tperm, grids, cstart;  // grid-pruned search of the batch entry point
-    GridIndex* grid = nullptr;  // grow-only uniform-grid index of the stand-alone queries
+    GridIndex* grid = nullptr;    // grow-only uniform-grid index of the stand-alone queries
+    // pinned staging of the offset arrays, so that a stream-ordered call can return before they are consumed
+    int64_t* h_off = nullptr;
+    size_t h_off_cap = 0;
+    hipEvent_t h_off_free = nullptr;  // recorded behind the last copy out of h_off
+    icpx_ctx* fallback = nullptr;     // handle that runs the pairs of a batch the fused kernel cannot take
+    int fb_dim = 0, fb_method = -1;
+    int stage_offsets(int64_t entries) {
+        if (h_off_free) ICPX_HIP(hipEventSynchronize(h_off_free));
+        if (static_cast<size_t>(entries) > h_off_cap) {
+            if (h_off) ICPX_HIP(hipHostFree(h_off));
+            h_off = nullptr;
+            h_off_cap = 0;
+            const size_t want = static_cast<size_t>(entries) + static_cast<size_t>(entries) / 4 + 64;
+            ICPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_off), sizeof(int64_t) * want, hipHostMallocDefault));
+            h_off_cap = want;
+        }
+        if (!h_off_free) ICPX_HIP(hipEventCreateWithFlags(&h_off_free, hipEventDisableTiming));
+        return ICPX_OK;
+    }
 };
-Workspace& workspace(int device) {
-    static std::mutex mu;
-    static std::unordered_map<int, Workspace*> ws;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = ws.find(device);
-    if (it == ws.end()) it = ws.emplace(device, new Workspace()).first;
+struct WsKey {
+    int device;
+    hipStream_t stream;
+    bool operator==(const WsKey& o) const { return device == o.device && stream == o.stream; }
+};
+struct WsKeyHash {
+    size_t operator()(const WsKey& k) const {
+        return std::hash<const void*>()(static_cast<const void*>(k.stream)) * 31u + static_cast<size_t>(k.device);
+    }
+};
+std::mutex g_ws_mu;
+std::unordered_map<WsKey, Workspace*, WsKeyHash> g_ws;
+Workspace& workspace(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    const WsKey key{device, stream};
+    auto it = g_ws.find(key);
+    if (it == g_ws.end()) it = g_ws.emplace(key, new Workspace()).first;
     return *it->second;
 }
 
@@ -313,13 +388,12 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     // A single pair in the fused kernel runs on ONE compute unit; beyond a modest size the
     // multi-kernel path (tiled correspondence over the whole chip) has the lower latency.
     // Development override: ICPX_FUSED_SINGLE_MAX = largest n*m that stays fused
-    double single_max = kFusedSingleMaxWork;
-    if (const char* e = std::getenv("ICPX_FUSED_SINGLE_MAX")) single_max = std::atof(e);
+    double single_max = knobs().fused_single_max;
+    if (single_max < 0.0) single_max = kFusedSingleMaxWork;
     // A single scan-sized pair iterates faster with the brute-force filter (scan1, 22 iterations: 1.6 ms
     // against 2.1 ms through the grid), so handles keep it; ICPX_PRUNE_HANDLES=1 sends them through the
     // grid-pruned kernels of the batch path (tests do, to run the whole handle suite over those kernels)
-    const char* ph = std::getenv("ICPX_PRUNE_HANDLES");
-    const bool prune_handles = ph && ph[0] == '1';
+    const bool prune_handles = knobs().prune_handles != 0;
     bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles) &&
                  static_cast<double>(n) * static_cast<double>(m) <= single_max &&
                  h->method != ICPX_FEATURE_AWARE &&  // feature_aware and the opt-in corrected modes run on
@@ -333,126 +407,41 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     return ICPX_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int icpx_version(void) { return ICPX_VERSION; }
-
-const char* icpx_last_error(void) { return last_error_ref().c_str(); }
-
-void icpx_default_params(icpx_params* p) {
-    if (!p) return;
-    p->overlap_rate = 0.9;  // trimmed.cpp:28
-    p->max_distance = 1.0;  // trimmed_3d.cpp:27
-    p->nn_mode = ICPX_NN_AUTO;
-    p->feature_weight = 0.7;       // feature_aware.cpp:23
-    p->symmetric_neighbors = 10;   // feature_aware.cpp:24
-    p->flags = 0;
-    p->device = -1;
-    p->stream = nullptr;
-}
-
-int icpx_init(int device) {
-    int dev = 0;
-    ICPX_TRY(resolve_device(device, &dev));
-    DeviceGuard g;
-    ICPX_TRY(g.enter(dev));
-    DeviceInfo* di = nullptr;
-    ICPX_TRY(device_info(dev, &di));
-    ICPX_HIP(hipFree(nullptr));
-    return ICPX_OK;
-}
-
-int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out) {
-    if (!out) return fail(ICPX_ERR_INVALID, "null out handle");
-    *out = nullptr;
-    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
-    if (method != ICPX_VANILLA && method != ICPX_TRIMMED && method != ICPX_FEATURE_AWARE)
-        return fail(ICPX_ERR_INVALID, "unknown method %d", method);
-    if (method == ICPX_FEATURE_AWARE && dim != 2)
-        return fail(ICPX_ERR_INVALID, "feature_aware is an ICP2 method (lib/icp/icp.cpp:17-21)");
-    icpx_params prm;
-    icpx_default_params(&prm);
-    if (params) prm = *params;
-    if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_GRID)
-        return fail(ICPX_ERR_INVALID, "unknown nn_mode %d", prm.nn_mode);
-    if (prm.flags < 0 || prm.flags > 7) return fail(ICPX_ERR_INVALID, "unknown flags %d", prm.flags);
-    int dev = 0;
-    ICPX_TRY(resolve_device(prm.device, &dev));
-    DeviceInfo* di = nullptr;
-    ICPX_TRY(device_info(dev, &di));
-    icpx_ctx* h = new (std::nothrow) icpx_ctx();
-    if (!h) return fail(ICPX_ERR_NOMEM, "out of host memory");
-    h->dim = dim;
-    h->method = method;
-    h->prm = prm;
-    h->device = dev;
-    h->stream = static_cast<hipStream_t>(prm.stream);
-    *out = h;
-    return ICPX_OK;
-}
-
-int icpx_destroy(icpx_handle h) {
-    if (!h) return ICPX_OK;
-    DeviceGuard g;
-    (void)g.enter(h->device);
-    (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->src, &h->dst, &h->cur, &h->off, &h->guess, &h->m_point, &h->m_pair,
-                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart})
-        b->release();
-    if (h->lg) large_destroy(h->lg);
-    delete h;
-    return ICPX_OK;
-}
-
-int icpx_begin(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
-               const double* guess) {
-    ICPX_TRY(check_handle(h));
-    DeviceGuard g;
-    ICPX_TRY(g.enter(h->device));
-    DeviceInfo* di = nullptr;
-    ICPX_TRY(device_info(h->device, &di));
-    ICPX_TRY(begin_common(h, source, n, target, m, guess));
-    if (h->large) {
-        if (!h->lg) ICPX_TRY(large_create(h->dim, h->method, h->prm, di->clock_to_s, h->stream, &h->lg));
-        ICPX_TRY(large_begin(h->lg, source, n, target, m, guess));
-        h->n = n;
-        h->m = m;
-    } else {
-        ICPX_TRY(upload_pair(h, source, n, target, m, guess));
-        PairBatch pb;
-        fill_batch(h, pb, *di);
-        pb.do_setup = 1;
-        pb.check = 0;
-        pb.max_steps = 0;
-        ICPX_TRY(launch_pairs(pb, 1, h->geom, h->stream));
+// Nothing may throw across the C ABI (icpx.h): std::string / std::vector / unordered_map / new inside the
+// entry points can, so every entry point runs its body through this.
+template <typename F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { return fail(ICPX_ERR_NOMEM, "out of host memory"); } catch (...) { return ICPX_ERR_NOMEM; }
+    } catch (const std::exception& e) {
+        try { return fail(ICPX_ERR_HIP, "unexpected exception: %s", e.what()); } catch (...) { return ICPX_ERR_HIP; }
+    } catch (...) {
+        return ICPX_ERR_HIP;
     }
-    h->begun = true;
+}
+
+// ICPDriver's loop is a HOST loop in the reference (driver.h:63) and can be interrupted; here it runs
+// inside one kernel, so criteria under which it can never end are rejected up front.
+int check_criteria(const icpx_criteria* c) {
+    if (!(c->has & (ICPX_HAS_MAX_ITER | ICPX_HAS_TIME_LIMIT)))
+        return fail(ICPX_ERR_INVALID,
+                    "criteria need max_iterations or a time limit: the converge loop runs on the device and could not be "
+                    "interrupted (the reference's loop without them never ends either, driver.h:43-44)");
+    if ((c->has & ICPX_HAS_MIN_ITER) && (c->has & ICPX_HAS_MAX_ITER) && c->min_iterations > c->max_iterations)
+        return fail(ICPX_ERR_INVALID, "min_iterations > max_iterations (driver.h:81,91 assert this)");
+    if ((c->has & ICPX_HAS_TIME_LIMIT) && !(c->time_limit_s == c->time_limit_s))
+        return fail(ICPX_ERR_INVALID, "time limit is NaN");
     return ICPX_OK;
 }
 
-int icpx_iterate(icpx_handle h) {
-    ICPX_TRY(check_handle(h));
-    if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_iterate before icpx_begin");
-    DeviceGuard g;
-    ICPX_TRY(g.enter(h->device));
-    DeviceInfo* di = nullptr;
-    ICPX_TRY(device_info(h->device, &di));
-    if (h->large) return large_iterate(h->lg);
-    PairBatch pb;
-    fill_batch(h, pb, *di);
-    pb.do_setup = 0;
-    pb.check = 0;
-    pb.max_steps = 1;
-    return launch_pairs(pb, 1, h->geom, h->stream);
-}
-
-int icpx_converge(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
+int converge_impl(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
                   const double* guess, const icpx_criteria* criteria, icpx_state* out) {
     auto t0 = std::chrono::steady_clock::now();  // driver.h:53
     ICPX_TRY(check_handle(h));
     if (!criteria || !out) return fail(ICPX_ERR_INVALID, "null criteria/out");
+    ICPX_TRY(check_criteria(criteria));
     DeviceGuard g;
     ICPX_TRY(g.enter(h->device));
     DeviceInfo* di = nullptr;
@@ -481,7 +470,507 @@ int icpx_converge(icpx_handle h, const double* source, int64_t n, const double* 
     return ICPX_OK;
 }
 
+
+// ---- batches ----------------------------------------------------------------------------------
+
+// device memory a fused batch launch needs beyond its inputs and outputs
+struct BatchScratch {
+    int64_t* soff;      // n_pairs + 1 source offsets
+    int64_t* doff;      // n_pairs + 1 target offsets
+    PairState* states;  // n_pairs
+    int32_t* sched;     // 2 * (n_pairs + 1) scheduler words (every fused run takes its pairs + 1)
+    double* cur;        // 3D: n_total running clouds
+    int32_t* seeds;     // n_total previous neighbours
+    uint16_t* tperm;    // m_total cell order of the targets
+    PairGrid* grids;    // n_pairs
+    uint16_t* cstart;   // n_pairs x kGridTable
+};
+
+struct BatchCall {
+    int dim, method;
+    icpx_params prm;
+    int64_t n_pairs;
+    const double* d_src;    // device
+    const double* d_dst;    // device
+    const double* d_guess;  // device or null
+    const int64_t* h_soff;  // host
+    const int64_t* h_doff;  // host
+    icpx_criteria crit;
+    icpx_state* d_out;      // device
+};
+
+// pairs [lo, hi) of the call through ONE fused launch (they all fit `geom`)
+int enqueue_fused_run(const BatchCall& c, int64_t lo, int64_t hi, int64_t run_index, const PairGeom& geom,
+                      const BatchScratch& sc, const DeviceInfo& di, hipStream_t stream,
+                      std::chrono::steady_clock::time_point t0) {
+    const int XN = (c.dim + 1) * (c.dim + 1);
+    const int64_t cnt = hi - lo;
+    int64_t m_max = 0;
+    for (int64_t p = lo; p < hi; p++) m_max = std::max(m_max, c.h_doff[p + 1] - c.h_doff[p]);
+    PairBatch pb;
+    std::memset(&pb, 0, sizeof(pb));
+    pb.dim = c.dim;
+    pb.method = c.method;
+    pb.src = c.d_src;
+    pb.src_off = sc.soff + lo;
+    pb.dst = c.d_dst;
+    pb.dst_off = sc.doff + lo;
+    pb.guesses = c.d_guess ? c.d_guess + lo * XN : nullptr;
+    pb.states = sc.states + lo;
+    pb.out_states = c.d_out + lo;
+    pb.crit = c.crit;
+    pb.overlap_rate = c.prm.overlap_rate;
+    pb.max_distance = c.prm.max_distance;
+    pb.clock_to_s = di.clock_to_s;
+    pb.do_setup = 1;
+    pb.check = 1;
+    pb.max_steps = UINT64_MAX;
+    // scheduler words (launch_one decides whether to use them) and, for 3D, the running clouds
+    // that a pair carries from one workgroup to the next
+    pb.sched_state = sc.sched + lo + run_index;
+    if (c.dim == 3) pb.cur = sc.cur;
+    if (geom.filter || geom.prune) pb.seeds = sc.seeds;  // the seeded search's previous neighbours travel with the pair
+    if (geom.prune) {
+        const size_t perm_lds = 512 + 8 * static_cast<size_t>(kGridMaxCells + 4);
+        auto pk = c.dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
+        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(cnt)), dim3(m_max >= 2048 ? 512 : 256), perm_lds, stream, c.d_dst,
+                           sc.doff + lo, sc.tperm, sc.grids + lo, sc.cstart + lo * kGridTable);
+        ICPX_HIP(hipGetLastError());
+        pb.tperm = sc.tperm;
+        pb.grids = sc.grids + lo;
+        pb.cstart = sc.cstart + lo * kGridTable;
+    }
+    pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    PairGeom g = geom;
+    return launch_pairs(pb, cnt, g, stream);
+}
+
+// Splits the pairs of a call into maximal runs that fit ONE fused geometry (each run = one launch) and
+// single pairs that do not (too many points for the fused kernel, feature_aware, opt-in flags): those go
+// through `fallback` (a handle on the multi-kernel path), or fail the call when there is none.
+struct BatchRun {
+    int64_t lo, hi;
+    bool fused;
+    PairGeom geom;
+};
+template <typename Runs>
+void plan_batch(const BatchCall& c, Runs& runs) {
+    const bool never_fused = c.method == ICPX_FEATURE_AWARE || c.prm.flags != 0;
+    // geometry of the whole call first: most batches are one run
+    int64_t p = 0;
+    while (p < c.n_pairs) {
+        PairGeom g1;
+        const bool fits = !never_fused && fused_fits(c.dim, c.method, c.h_soff[p + 1] - c.h_soff[p],
+                                                     c.h_doff[p + 1] - c.h_doff[p], &g1, false, true);
+        int64_t q = p + 1;
+        if (!fits) {
+            runs.push_back(BatchRun{p, q, false, PairGeom{}});
+            p = q;
+            continue;
+        }
+        int64_t n_max = c.h_soff[p + 1] - c.h_soff[p], m_max = c.h_doff[p + 1] - c.h_doff[p];
+        PairGeom g = g1;
+        while (q < c.n_pairs) {
+            const int64_t n = c.h_soff[q + 1] - c.h_soff[q], m = c.h_doff[q + 1] - c.h_doff[q];
+            PairGeom gq;
+            if (!fused_fits(c.dim, c.method, n, m, &gq, false, true)) break;
+            PairGeom gj;
+            if (!fused_fits(c.dim, c.method, std::max(n_max, n), std::max(m_max, m), &gj, false, true)) break;
+            n_max = std::max(n_max, n);
+            m_max = std::max(m_max, m);
+            g = gj;
+            q++;
+        }
+        runs.push_back(BatchRun{p, q, true, g});
+        p = q;
+    }
+}
+
+int validate_batch_args(int dim, int method, const icpx_params* params, int64_t n_pairs, const double* source,
+                        const int64_t* source_offsets, const double* target, const int64_t* target_offsets,
+                        const icpx_criteria* criteria, icpx_state* out_states) {
+    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (method != ICPX_VANILLA && method != ICPX_TRIMMED && method != ICPX_FEATURE_AWARE)
+        return fail(ICPX_ERR_INVALID, "unknown method %d", method);
+    if (method == ICPX_FEATURE_AWARE && dim != 2)
+        return fail(ICPX_ERR_INVALID, "feature_aware is an ICP2 method (lib/icp/icp.cpp:17-21)");
+    if (params && (params->flags < 0 || params->flags > 7)) return fail(ICPX_ERR_INVALID, "unknown flags %d", params->flags);
+    if (n_pairs < 0) return fail(ICPX_ERR_INVALID, "negative n_pairs");
+    if (n_pairs == 0) return ICPX_OK;
+    if (!source_offsets || !target_offsets || !criteria || !out_states)
+        return fail(ICPX_ERR_INVALID, "null offsets/criteria/out_states");
+    ICPX_TRY(check_criteria(criteria));
+    if (n_pairs > (1 << 30)) return fail(ICPX_ERR_UNSUPPORTED, "too many pairs");
+    for (int64_t p = 0; p < n_pairs; p++) {
+        if (source_offsets[p + 1] < source_offsets[p] || target_offsets[p + 1] < target_offsets[p])
+            return fail(ICPX_ERR_INVALID, "offsets must be non-decreasing (pair %lld)", (long long)p);
+    }
+    if (source_offsets[0] < 0 || target_offsets[0] < 0) return fail(ICPX_ERR_INVALID, "negative offset");
+    if ((source_offsets[n_pairs] > source_offsets[0] && !source) || (target_offsets[n_pairs] > target_offsets[0] && !target))
+        return fail(ICPX_ERR_INVALID, "null source/target");
+    return ICPX_OK;
+}
+
+// one device, one stream; see icpx_converge_batch in icpx.h
+int converge_batch_impl(int dim, int method, const icpx_params* params, int64_t n_pairs, const double* source,
+                        const int64_t* source_offsets, const double* target, const int64_t* target_offsets,
+                        const double* guesses, const icpx_criteria* criteria, icpx_state* out_states) {
+    auto t0 = std::chrono::steady_clock::now();
+    ICPX_TRY(validate_batch_args(dim, method, params, n_pairs, source, source_offsets, target, target_offsets, criteria,
+                                 out_states));
+    if (n_pairs == 0) return ICPX_OK;
+    icpx_params prm;
+    icpx_default_params(&prm);
+    if (params) prm = *params;
+    int dev = 0;
+    ICPX_TRY(resolve_device(prm.device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    hipStream_t stream = static_cast<hipStream_t>(prm.stream);
+    const int64_t n_total = source_offsets[n_pairs], m_total = target_offsets[n_pairs];
+    const int XN = (dim + 1) * (dim + 1);
+
+    Workspace& ws = workspace(dev, stream);
+    std::lock_guard<std::mutex> lk(ws.mu);
+    BatchCall c;
+    c.dim = dim;
+    c.method = method;
+    c.prm = prm;
+    c.n_pairs = n_pairs;
+    c.h_soff = source_offsets;
+    c.h_doff = target_offsets;
+    c.crit = *criteria;
+    std::vector<BatchRun> runs;
+    plan_batch(c, runs);
+    bool any_fused = false, any_fallback = false;
+    for (const BatchRun& r : runs) (r.fused ? any_fused : any_fallback) = true;
+
+    // a call whose arrays all live on the device is stream-ordered (returns once the work is enqueued)
+    bool must_sync = any_fallback;
+    c.d_src = source;
+    c.d_dst = target;
+    c.d_guess = guesses;
+    c.d_out = out_states;
+    if (any_fused) {
+        if (n_total > 0 && !is_device_ptr(source)) {
+            ICPX_TRY(ws.src.reserve(sizeof(double) * dim * n_total));
+            ICPX_HIP(hipMemcpyAsync(ws.src.p, source, sizeof(double) * dim * n_total, hipMemcpyHostToDevice, stream));
+            c.d_src = ws.src.as<double>();
+            must_sync = true;
+        }
+        if (m_total > 0 && !is_device_ptr(target)) {
+            ICPX_TRY(ws.dst.reserve(sizeof(double) * dim * m_total));
+            ICPX_HIP(hipMemcpyAsync(ws.dst.p, target, sizeof(double) * dim * m_total, hipMemcpyHostToDevice, stream));
+            c.d_dst = ws.dst.as<double>();
+            must_sync = true;
+        }
+        if (guesses && !is_device_ptr(guesses)) {
+            ICPX_TRY(ws.guesses.reserve(sizeof(double) * XN * n_pairs));
+            ICPX_HIP(hipMemcpyAsync(ws.guesses.p, guesses, sizeof(double) * XN * n_pairs, hipMemcpyHostToDevice, stream));
+            c.d_guess = ws.guesses.as<double>();
+            must_sync = true;
+        }
+    }
+    const bool out_on_device = is_device_ptr(out_states);
+    if (!out_on_device) {
+        ICPX_TRY(ws.out.reserve(sizeof(icpx_state) * n_pairs));
+        c.d_out = ws.out.as<icpx_state>();
+        must_sync = true;
+    }
+    if (any_fused) {
+        // offsets: through pinned staging, so the caller's arrays are free when the call returns
+        ICPX_TRY(ws.stage_offsets(2 * (n_pairs + 1)));
+        std::memcpy(ws.h_off, source_offsets, sizeof(int64_t) * (n_pairs + 1));
+        std::memcpy(ws.h_off + n_pairs + 1, target_offsets, sizeof(int64_t) * (n_pairs + 1));
+        ICPX_TRY(ws.soff.reserve(sizeof(int64_t) * 2 * (n_pairs + 1)));
+        ICPX_HIP(hipMemcpyAsync(ws.soff.p, ws.h_off, sizeof(int64_t) * 2 * (n_pairs + 1), hipMemcpyHostToDevice, stream));
+        ICPX_HIP(hipEventRecord(ws.h_off_free, stream));
+        ICPX_TRY(ws.states.reserve(sizeof(PairState) * n_pairs));
+        ICPX_TRY(ws.sched.reserve(sizeof(int32_t) * 2 * (n_pairs + 1)));
+        if (dim == 3) ICPX_TRY(ws.cur.reserve(sizeof(double) * 3 * (n_total > 0 ? n_total : 1)));
+        ICPX_TRY(ws.seeds.reserve(sizeof(int32_t) * (n_total > 0 ? n_total : 1)));
+        ICPX_TRY(ws.tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
+        ICPX_TRY(ws.grids.reserve(sizeof(PairGrid) * n_pairs));
+        ICPX_TRY(ws.cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
+    }
+    BatchScratch sc;
+    sc.soff = ws.soff.as<int64_t>();
+    sc.doff = sc.soff ? sc.soff + n_pairs + 1 : nullptr;
+    sc.states = ws.states.as<PairState>();
+    sc.sched = ws.sched.as<int32_t>();
+    sc.cur = ws.cur.as<double>();
+    sc.seeds = ws.seeds.as<int32_t>();
+    sc.tperm = ws.tperm.as<uint16_t>();
+    sc.grids = ws.grids.as<PairGrid>();
+    sc.cstart = ws.cstart.as<uint16_t>();
+
+    int64_t run_index = 0;
+    for (const BatchRun& r : runs) {
+        if (r.fused) {
+            ICPX_TRY(enqueue_fused_run(c, r.lo, r.hi, run_index++, r.geom, sc, *di, stream, t0));
+            continue;
+        }
+        // a pair the fused kernel cannot take: the multi-kernel path, through a handle of this workspace
+        if (!ws.fallback || ws.fb_dim != dim || ws.fb_method != method || ws.fallback->prm.flags != prm.flags ||
+            ws.fallback->prm.overlap_rate != prm.overlap_rate || ws.fallback->prm.max_distance != prm.max_distance ||
+            ws.fallback->prm.feature_weight != prm.feature_weight ||
+            ws.fallback->prm.symmetric_neighbors != prm.symmetric_neighbors || ws.fallback->prm.nn_mode != prm.nn_mode) {
+            if (ws.fallback) (void)icpx_destroy(ws.fallback);
+            ws.fallback = nullptr;
+            icpx_params fp = prm;
+            fp.device = dev;
+            ICPX_TRY(icpx_create(dim, method, &fp, &ws.fallback));
+            ws.fb_dim = dim;
+            ws.fb_method = method;
+        }
+        const int64_t p = r.lo;
+        double ident[16] = {0};
+        for (int e = 0; e <= dim; e++) ident[e * (dim + 2)] = 1.0;
+        double gbuf[16];
+        const double* gp = ident;
+        if (guesses) {
+            ICPX_HIP(hipMemcpy(gbuf, guesses + p * XN, sizeof(double) * XN, hipMemcpyDefault));
+            gp = gbuf;
+        }
+        icpx_state st;
+        std::memset(&st, 0, sizeof(st));
+        ICPX_TRY(converge_impl(ws.fallback, source ? source + source_offsets[p] * dim : nullptr,
+                               source_offsets[p + 1] - source_offsets[p], target ? target + target_offsets[p] * dim : nullptr,
+                               target_offsets[p + 1] - target_offsets[p], gp, criteria, &st));
+        ICPX_HIP(hipMemcpy(c.d_out + p, &st, sizeof(st), hipMemcpyDefault));
+    }
+    if (!out_on_device)
+        ICPX_HIP(hipMemcpyAsync(out_states, c.d_out, sizeof(icpx_state) * n_pairs, hipMemcpyDeviceToHost, stream));
+    if (must_sync) ICPX_HIP(hipStreamSynchronize(stream));
+    return ICPX_OK;
+}
+
+
+// ---- several devices --------------------------------------------------------------------------
+
+std::mutex g_multi_mu;
+std::unordered_map<long long, hipStream_t> g_multi_streams;  // (device, shard slot) -> stream of that shard
+int multi_stream(int dev, int slot, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    const long long key = static_cast<long long>(dev) * 4096 + slot;
+    auto it = g_multi_streams.find(key);
+    if (it == g_multi_streams.end()) {
+        DeviceGuard g;
+        ICPX_TRY(g.enter(dev));
+        hipStream_t st = nullptr;
+        ICPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        it = g_multi_streams.emplace(key, st).first;
+    }
+    *out = it->second;
+    return ICPX_OK;
+}
+
+// contiguous block of pairs of shard r out of `shards`: pair p -> shard floor(p * shards / n_pairs)
+// (icp_amd/shard.py computes the same bounds for the one-process-per-GPU launch)
+void shard_bounds(int64_t n_pairs, int r, int shards, int64_t* lo, int64_t* hi) {
+    *lo = (n_pairs * r + shards - 1) / shards;
+    *hi = (n_pairs * (r + 1) + shards - 1) / shards;
+}
+
+int converge_batch_multi_impl(int dim, int method, const icpx_params* params, int device_count, const int* devices,
+                              int64_t n_pairs, const double* source, const int64_t* source_offsets, const double* target,
+                              const int64_t* target_offsets, const double* guesses, const icpx_criteria* criteria,
+                              icpx_state* out_states) {
+    if (device_count < 1 || device_count > 4096) return fail(ICPX_ERR_INVALID, "device_count must be in [1, 4096]");
+    ICPX_TRY(validate_batch_args(dim, method, params, n_pairs, source, source_offsets, target, target_offsets, criteria,
+                                 out_states));
+    if (n_pairs == 0) return ICPX_OK;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        (void)hipGetLastError();
+        return fail(ICPX_ERR_NO_DEVICE, "no HIP device visible; icpx has no CPU path");
+    }
+    std::vector<int> devs(device_count);
+    std::vector<int> slot(device_count, 0);
+    for (int r = 0; r < device_count; r++) {
+        devs[r] = devices ? devices[r] : r;
+        if (devs[r] < 0 || devs[r] >= visible)
+            return fail(ICPX_ERR_INVALID, "device %d out of range (%d visible)", devs[r], visible);
+        for (int q = 0; q < r; q++) slot[r] += devs[q] == devs[r];  // a device listed twice gets two streams
+    }
+    icpx_params base;
+    icpx_default_params(&base);
+    if (params) base = *params;
+    const int XN = (dim + 1) * (dim + 1);
+    std::vector<int> rc(device_count, ICPX_OK);
+    std::vector<std::string> err(device_count);
+    auto work = [&](int r) {
+        rc[r] = guarded([&]() -> int {
+            int64_t lo, hi;
+            shard_bounds(n_pairs, r, device_count, &lo, &hi);
+            if (hi <= lo) return ICPX_OK;
+            icpx_params prm = base;
+            prm.device = devs[r];
+            hipStream_t st = nullptr;
+            ICPX_TRY(multi_stream(devs[r], slot[r], &st));
+            prm.stream = st;
+            // the shard's offsets count from its first point
+            std::vector<int64_t> so(hi - lo + 1), to(hi - lo + 1);
+            for (int64_t p = lo; p <= hi; p++) {
+                so[p - lo] = source_offsets[p] - source_offsets[lo];
+                to[p - lo] = target_offsets[p] - target_offsets[lo];
+            }
+            int rcode = converge_batch_impl(dim, method, &prm, hi - lo, source ? source + source_offsets[lo] * dim : nullptr,
+                                            so.data(), target ? target + target_offsets[lo] * dim : nullptr, to.data(),
+                                            guesses ? guesses + lo * XN : nullptr, criteria, out_states + lo);
+            if (rcode != ICPX_OK) return rcode;
+            // the gather: every shard's records are in the caller's array when its stream has drained
+            DeviceGuard g;
+            ICPX_TRY(g.enter(devs[r]));
+            ICPX_HIP(hipStreamSynchronize(st));
+            return ICPX_OK;
+        });
+        if (rc[r] != ICPX_OK) err[r] = last_error_ref();
+    };
+    // one host thread per shard (the calling thread takes shard 0)
+    std::vector<std::thread> threads;
+    for (int r = 1; r < device_count; r++) threads.emplace_back(work, r);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (int r = 0; r < device_count; r++)
+        if (rc[r] != ICPX_OK) return fail(rc[r], "shard %d (device %d): %s", r, devs[r], err[r].c_str());
+    return ICPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icpx_version(void) { return ICPX_VERSION; }
+
+const char* icpx_last_error(void) { return last_error_ref().c_str(); }
+
+void icpx_default_params(icpx_params* p) {
+    if (!p) return;
+    p->overlap_rate = 0.9;  // trimmed.cpp:28
+    p->max_distance = 1.0;  // trimmed_3d.cpp:27
+    p->nn_mode = ICPX_NN_AUTO;
+    p->feature_weight = 0.7;       // feature_aware.cpp:23
+    p->symmetric_neighbors = 10;   // feature_aware.cpp:24
+    p->flags = 0;
+    p->device = -1;
+    p->stream = nullptr;
+}
+
+int icpx_init(int device) {
+    return guarded([&]() -> int {
+    int dev = 0;
+    ICPX_TRY(resolve_device(device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    ICPX_HIP(hipFree(nullptr));
+    return ICPX_OK;
+    });
+}
+
+int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out) {
+    return guarded([&]() -> int {
+    if (!out) return fail(ICPX_ERR_INVALID, "null out handle");
+    *out = nullptr;
+    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (method != ICPX_VANILLA && method != ICPX_TRIMMED && method != ICPX_FEATURE_AWARE)
+        return fail(ICPX_ERR_INVALID, "unknown method %d", method);
+    if (method == ICPX_FEATURE_AWARE && dim != 2)
+        return fail(ICPX_ERR_INVALID, "feature_aware is an ICP2 method (lib/icp/icp.cpp:17-21)");
+    icpx_params prm;
+    icpx_default_params(&prm);
+    if (params) prm = *params;
+    if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_GRID)
+        return fail(ICPX_ERR_INVALID, "unknown nn_mode %d", prm.nn_mode);
+    if (prm.flags < 0 || prm.flags > 7) return fail(ICPX_ERR_INVALID, "unknown flags %d", prm.flags);
+    int dev = 0;
+    ICPX_TRY(resolve_device(prm.device, &dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    icpx_ctx* h = new (std::nothrow) icpx_ctx();
+    if (!h) return fail(ICPX_ERR_NOMEM, "out of host memory");
+    h->dim = dim;
+    h->method = method;
+    h->prm = prm;
+    h->device = dev;
+    h->stream = static_cast<hipStream_t>(prm.stream);
+    *out = h;
+    return ICPX_OK;
+    });
+}
+
+int icpx_destroy(icpx_handle h) {
+    return guarded([&]() -> int {
+    if (!h) return ICPX_OK;
+    DeviceGuard g;
+    (void)g.enter(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (DevBuf* b : {&h->src, &h->dst, &h->cur, &h->off, &h->guess, &h->m_point, &h->m_pair,
+                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart})
+        b->release();
+    if (h->lg) large_destroy(h->lg);
+    delete h;
+    return ICPX_OK;
+    });
+}
+
+int icpx_begin(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
+               const double* guess) {
+    return guarded([&]() -> int {
+    ICPX_TRY(check_handle(h));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(h->device, &di));
+    ICPX_TRY(begin_common(h, source, n, target, m, guess));
+    if (h->large) {
+        if (!h->lg) ICPX_TRY(large_create(h->dim, h->method, h->prm, di->clock_to_s, h->stream, &h->lg));
+        ICPX_TRY(large_begin(h->lg, source, n, target, m, guess));
+        h->n = n;
+        h->m = m;
+    } else {
+        ICPX_TRY(upload_pair(h, source, n, target, m, guess));
+        PairBatch pb;
+        fill_batch(h, pb, *di);
+        pb.do_setup = 1;
+        pb.check = 0;
+        pb.max_steps = 0;
+        ICPX_TRY(launch_pairs(pb, 1, h->geom, h->stream));
+    }
+    h->begun = true;
+    return ICPX_OK;
+    });
+}
+
+int icpx_iterate(icpx_handle h) {
+    return guarded([&]() -> int {
+    ICPX_TRY(check_handle(h));
+    if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_iterate before icpx_begin");
+    DeviceGuard g;
+    ICPX_TRY(g.enter(h->device));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(h->device, &di));
+    if (h->large) return large_iterate(h->lg);
+    PairBatch pb;
+    fill_batch(h, pb, *di);
+    pb.do_setup = 0;
+    pb.check = 0;
+    pb.max_steps = 1;
+    return launch_pairs(pb, 1, h->geom, h->stream);
+    });
+}
+
+int icpx_converge(icpx_handle h, const double* source, int64_t n, const double* target, int64_t m,
+                  const double* guess, const icpx_criteria* criteria, icpx_state* out) {
+    return guarded([&]() -> int { return converge_impl(h, source, n, target, m, guess, criteria, out); });
+}
+
 int icpx_cost(icpx_handle h, double* out) {
+    return guarded([&]() -> int {
     ICPX_TRY(check_handle(h));
     if (!out) return fail(ICPX_ERR_INVALID, "null out");
     if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_cost before icpx_begin");
@@ -491,9 +980,11 @@ int icpx_cost(icpx_handle h, double* out) {
     ICPX_HIP(hipMemcpyAsync(out, &h->state.as<PairState>()->cost, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     ICPX_HIP(hipStreamSynchronize(h->stream));
     return ICPX_OK;
+    });
 }
 
 int icpx_transform(icpx_handle h, double* out) {
+    return guarded([&]() -> int {
     ICPX_TRY(check_handle(h));
     if (!out) return fail(ICPX_ERR_INVALID, "null out");
     if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_transform before icpx_begin");
@@ -504,16 +995,20 @@ int icpx_transform(icpx_handle h, double* out) {
     ICPX_HIP(hipMemcpyAsync(out, h->state.as<PairState>()->transform, sizeof(double) * XN, hipMemcpyDeviceToHost, h->stream));
     ICPX_HIP(hipStreamSynchronize(h->stream));
     return ICPX_OK;
+    });
 }
 
 int icpx_sizes(icpx_handle h, int64_t* n, int64_t* m) {
+    return guarded([&]() -> int {
     ICPX_TRY(check_handle(h));
     if (n) *n = h->n;
     if (m) *m = h->m;
     return ICPX_OK;
+    });
 }
 
 int icpx_matches(icpx_handle h, int64_t* point, int64_t* pair, double* cost) {
+    return guarded([&]() -> int {
     ICPX_TRY(check_handle(h));
     if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_matches before icpx_begin");
     const int64_t n = h->n;
@@ -538,9 +1033,11 @@ int icpx_matches(icpx_handle h, int64_t* point, int64_t* pair, double* cost) {
     if (cost) ICPX_HIP(hipMemcpyAsync(cost, h->m_cost.p, sizeof(double) * n, hipMemcpyDefault, h->stream));
     ICPX_HIP(hipStreamSynchronize(h->stream));
     return ICPX_OK;
+    });
 }
 
 int icpx_debug_neighbors(icpx_handle h, int64_t* indices, double* distances) {
+    return guarded([&]() -> int {
     ICPX_TRY(check_handle(h));
     if (!h->begun) return fail(ICPX_ERR_STATE, "icpx_debug_neighbors before icpx_begin");
     if (h->dim != 3) return fail(ICPX_ERR_INVALID, "neighbors exist for the 3D methods only");
@@ -553,6 +1050,7 @@ int icpx_debug_neighbors(icpx_handle h, int64_t* indices, double* distances) {
     if (distances) ICPX_HIP(hipMemcpyAsync(distances, h->m_cost.p, sizeof(double) * n, hipMemcpyDefault, h->stream));
     ICPX_HIP(hipStreamSynchronize(h->stream));
     return ICPX_OK;
+    });
 }
 
 int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t n_pairs,
@@ -560,127 +1058,25 @@ int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t 
                         const double* target, const int64_t* target_offsets,
                         const double* guesses, const icpx_criteria* criteria,
                         icpx_state* out_states) {
-    auto t0 = std::chrono::steady_clock::now();
-    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
-    if (method == ICPX_FEATURE_AWARE || (params && params->flags != 0))
-        return fail(ICPX_ERR_UNSUPPORTED,
-                    "icpx_converge_batch: feature_aware and the opt-in corrected modes run through handles (icpx_converge) only");
-    if (method != ICPX_VANILLA && method != ICPX_TRIMMED) return fail(ICPX_ERR_INVALID, "unknown method %d", method);
-    if (n_pairs < 0) return fail(ICPX_ERR_INVALID, "negative n_pairs");
-    if (n_pairs == 0) return ICPX_OK;
-    if (!source_offsets || !target_offsets || !criteria || !out_states)
-        return fail(ICPX_ERR_INVALID, "null offsets/criteria/out_states");
-    if (n_pairs > (1 << 30)) return fail(ICPX_ERR_UNSUPPORTED, "too many pairs");
-    icpx_params prm;
-    icpx_default_params(&prm);
-    if (params) prm = *params;
-    int dev = 0;
-    ICPX_TRY(resolve_device(prm.device, &dev));
-    DeviceGuard g;
-    ICPX_TRY(g.enter(dev));
-    DeviceInfo* di = nullptr;
-    ICPX_TRY(device_info(dev, &di));
-    hipStream_t stream = static_cast<hipStream_t>(prm.stream);
+    return guarded([&]() -> int {
+        return converge_batch_impl(dim, method, params, n_pairs, source, source_offsets, target, target_offsets, guesses,
+                                   criteria, out_states);
+    });
+}
 
-    int64_t n_max = 0, m_max = 0;
-    for (int64_t p = 0; p < n_pairs; p++) {
-        int64_t n = source_offsets[p + 1] - source_offsets[p];
-        int64_t m = target_offsets[p + 1] - target_offsets[p];
-        if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "offsets must be non-decreasing (pair %lld)", (long long)p);
-        if (n > n_max) n_max = n;
-        if (m > m_max) m_max = m;
-    }
-    const int64_t n_total = source_offsets[n_pairs], m_total = target_offsets[n_pairs];
-    if ((n_total > 0 && !source) || (m_total > 0 && !target)) return fail(ICPX_ERR_INVALID, "null source/target");
-    PairGeom geom;
-    if (!fused_fits(dim, method, n_max, m_max, &geom, false, true))
-        return fail(ICPX_ERR_UNSUPPORTED,
-                    "icpx_converge_batch: largest pair (%lld x %lld points) exceeds the fused kernel's limits; "
-                    "run such pairs through icpx_converge", (long long)n_max, (long long)m_max);
-
-    Workspace& ws = workspace(dev);
-    std::lock_guard<std::mutex> lk(ws.mu);
-    const int XN = (dim + 1) * (dim + 1);
-    const double* d_src = source;
-    const double* d_dst = target;
-    const double* d_guess = guesses;
-    if (n_total > 0 && !is_device_ptr(source)) {
-        ICPX_TRY(ws.src.reserve(sizeof(double) * dim * n_total));
-        ICPX_HIP(hipMemcpyAsync(ws.src.p, source, sizeof(double) * dim * n_total, hipMemcpyHostToDevice, stream));
-        d_src = ws.src.as<double>();
-    }
-    if (m_total > 0 && !is_device_ptr(target)) {
-        ICPX_TRY(ws.dst.reserve(sizeof(double) * dim * m_total));
-        ICPX_HIP(hipMemcpyAsync(ws.dst.p, target, sizeof(double) * dim * m_total, hipMemcpyHostToDevice, stream));
-        d_dst = ws.dst.as<double>();
-    }
-    if (guesses && !is_device_ptr(guesses)) {
-        ICPX_TRY(ws.guesses.reserve(sizeof(double) * XN * n_pairs));
-        ICPX_HIP(hipMemcpyAsync(ws.guesses.p, guesses, sizeof(double) * XN * n_pairs, hipMemcpyHostToDevice, stream));
-        d_guess = ws.guesses.as<double>();
-    }
-    ICPX_TRY(ws.soff.reserve(sizeof(int64_t) * (n_pairs + 1)));
-    ICPX_TRY(ws.doff.reserve(sizeof(int64_t) * (n_pairs + 1)));
-    ICPX_HIP(hipMemcpyAsync(ws.soff.p, source_offsets, sizeof(int64_t) * (n_pairs + 1), hipMemcpyHostToDevice, stream));
-    ICPX_HIP(hipMemcpyAsync(ws.doff.p, target_offsets, sizeof(int64_t) * (n_pairs + 1), hipMemcpyHostToDevice, stream));
-    ICPX_TRY(ws.states.reserve(sizeof(PairState) * n_pairs));
-    const bool out_on_device = is_device_ptr(out_states);
-    icpx_state* d_out = out_states;
-    if (!out_on_device) {
-        ICPX_TRY(ws.out.reserve(sizeof(icpx_state) * n_pairs));
-        d_out = ws.out.as<icpx_state>();
-    }
-
-    PairBatch pb;
-    std::memset(&pb, 0, sizeof(pb));
-    pb.dim = dim;
-    pb.method = method;
-    pb.src = d_src;
-    pb.src_off = ws.soff.as<int64_t>();
-    pb.dst = d_dst;
-    pb.dst_off = ws.doff.as<int64_t>();
-    pb.guesses = d_guess;
-    pb.states = ws.states.as<PairState>();
-    pb.out_states = d_out;
-    pb.crit = *criteria;
-    pb.overlap_rate = prm.overlap_rate;
-    pb.max_distance = prm.max_distance;
-    pb.clock_to_s = di->clock_to_s;
-    pb.do_setup = 1;
-    pb.check = 1;
-    pb.max_steps = UINT64_MAX;
-    // scheduler words (launch_one decides whether to use them) and, for 3D, the running clouds
-    // that a pair carries from one workgroup to the next
-    ICPX_TRY(ws.sched.reserve(sizeof(int32_t) * (n_pairs + 1)));
-    pb.sched_state = ws.sched.as<int32_t>();
-    if (dim == 3) {
-        ICPX_TRY(ws.cur.reserve(sizeof(double) * 3 * (n_total > 0 ? n_total : 1)));
-        pb.cur = ws.cur.as<double>();
-    }
-    if (geom.filter || geom.prune) {
-        // previous nearest neighbours: the filtered search's seeds travel with the pair too
-        ICPX_TRY(ws.seeds.reserve(sizeof(int32_t) * (n_total > 0 ? n_total : 1)));
-        pb.seeds = ws.seeds.as<int32_t>();
-    }
-    if (geom.prune) {
-        ICPX_TRY(enqueue_prepass(dim, n_pairs, m_max, m_total, d_dst, ws.doff.as<int64_t>(), ws.tperm, ws.grids, ws.cstart,
-                                 stream));
-        pb.tperm = ws.tperm.as<uint16_t>();
-        pb.grids = ws.grids.as<PairGrid>();
-        pb.cstart = ws.cstart.as<uint16_t>();
-    }
-    pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    ICPX_TRY(launch_pairs(pb, n_pairs, geom, stream));
-    if (!out_on_device) {
-        ICPX_HIP(hipMemcpyAsync(out_states, d_out, sizeof(icpx_state) * n_pairs, hipMemcpyDeviceToHost, stream));
-    }
-    // the offset arrays are the caller's host memory: finish the copies before returning
-    ICPX_HIP(hipStreamSynchronize(stream));
-    return ICPX_OK;
+int icpx_converge_batch_multi(int dim, int method, const icpx_params* params, int device_count, const int* devices,
+                              int64_t n_pairs, const double* source, const int64_t* source_offsets,
+                              const double* target, const int64_t* target_offsets, const double* guesses,
+                              const icpx_criteria* criteria, icpx_state* out_states) {
+    return guarded([&]() -> int {
+        return converge_batch_multi_impl(dim, method, params, device_count, devices, n_pairs, source, source_offsets,
+                                         target, target_offsets, guesses, criteria, out_states);
+    });
 }
 
 int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
                          int device, void* stream_, double* out) {
+    return guarded([&]() -> int {
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
     if (n <= 0 || m <= 0 || !queries || !targets || !out) return fail(ICPX_ERR_INVALID, "null or empty input");
     if (n > INT32_MAX / 4 || m > INT32_MAX / 4) return fail(ICPX_ERR_UNSUPPORTED, "cloud too large");
@@ -692,15 +1088,17 @@ int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double
     ICPX_TRY(device_info(dev, &di));
     if (!is_device_ptr(queries) || !is_device_ptr(targets))
         return fail(ICPX_ERR_INVALID, "icpx_nn_grid_profile takes device pointers");
-    Workspace& ws = workspace(dev);
+    Workspace& ws = workspace(dev, static_cast<hipStream_t>(stream_));
     std::lock_guard<std::mutex> lk(ws.mu);
     if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
     return grid_profile(ws.grid, dim, queries, n, targets, m, static_cast<hipStream_t>(stream_), out);
+    });
 }
 
 #ifdef ICPX_STATS
 // development builds only (-DICPX_STATS): read / reset the kernel statistics counters
 int icpx_debug_stats(unsigned long long* out, int reset) {
+    return guarded([&]() -> int {
     ICPX_HIP(hipDeviceSynchronize());
     unsigned long long acc[16] = {0};
     ICPX_TRY(stats_read_d2_plain(acc, reset));
@@ -709,11 +1107,21 @@ int icpx_debug_stats(unsigned long long* out, int reset) {
     ICPX_TRY(stats_read_d3_prune(acc, reset));
     if (out) std::memcpy(out, acc, sizeof(acc));
     return ICPX_OK;
+    });
 }
 #endif
 
+int icpx_debug_knob(const char* name, const char* value) {
+    return guarded([&]() -> int {
+    if (!name) return fail(ICPX_ERR_INVALID, "null knob name");
+    if (!set_knob(knobs(), name, value)) return fail(ICPX_ERR_INVALID, "unknown knob %s", name);
+    return ICPX_OK;
+    });
+}
+
 int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
             int64_t* idx, double* d2, int mode, int device, void* stream_) {
+    return guarded([&]() -> int {
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
     if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "negative cloud size");
     if (mode < ICPX_NN_AUTO || mode > ICPX_NN_GRID) return fail(ICPX_ERR_INVALID, "unknown nn mode %d", mode);
@@ -727,7 +1135,7 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
     DeviceInfo* di = nullptr;
     ICPX_TRY(device_info(dev, &di));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    Workspace& ws = workspace(dev);
+    Workspace& ws = workspace(dev, stream);
     std::lock_guard<std::mutex> lk(ws.mu);
 
     const double* d_q = queries;
@@ -763,8 +1171,7 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
     } else {
         // (query tiles) x (target splits) so that the launch fills the chip; f32 filter + exact
         // refinement (nn_tile_kernel).  ICPX_FILTER=0 (development) selects the plain f64 kernel.
-        const char* fe = std::getenv("ICPX_FILTER");
-        const bool plain = fe && fe[0] == '0';
+        const bool plain = knobs().filter == 0;
         const int per_tile = plain ? kNnThreads * kNnQpt : kNnThreads * kNnTileQpt;
         const int qblocks = static_cast<int>((n + per_tile - 1) / per_tile);
         int splits = (4 * di->cus + qblocks - 1) / qblocks;
@@ -827,6 +1234,7 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
     if (d2 && !d2_dev) ICPX_HIP(hipMemcpyAsync(d2, d_d2, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     ICPX_HIP(hipStreamSynchronize(stream));
     return ICPX_OK;
+    });
 }
 
 }  // extern "C"

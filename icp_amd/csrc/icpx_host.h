@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -24,6 +25,22 @@ inline int fail(int code, const char* fmt, ...) {
     last_error_ref() = buf;
     return code;
 }
+
+// Development knobs.  The ICPX_* environment variables are read ONCE, when the library is first used;
+// afterwards only icpx_debug_knob() (icpx.h) changes them.  Product calls read these atomics, never
+// the environment.
+struct Knobs {
+    std::atomic<int> prune{1};           // ICPX_PRUNE: 0 = batches use the brute-force filter instead of the grid-pruned search
+    std::atomic<int> filter{1};          // ICPX_FILTER: 0 = plain f64 brute force (no f32 candidate filter)
+    std::atomic<int> sched{-1};          // ICPX_SCHED: -1 auto, 0 never, 1 always (iteration-granular scheduler)
+    std::atomic<int> sched_steps{0};     // ICPX_SCHED_STEPS: iterations per scheduler task, 0 = default
+    std::atomic<int> prune_handles{0};   // ICPX_PRUNE_HANDLES: 1 = handles run the grid-pruned kernels too
+    std::atomic<int> no_group_sums{0};   // ICPX_NO_GROUP_SUMS: 1 = multi-kernel path always sums in 4096-point blocks
+    std::atomic<int> geom_qpt{0}, geom_threads{0};      // ICPX_GEOM="qpt,threads"
+    std::atomic<double> fused_single_max{-1.0};         // ICPX_FUSED_SINGLE_MAX: largest n*m of a handle that stays fused; < 0 = default
+    std::atomic<int> coop{1};            // ICPX_COOP: 0 = per-lane grid walk instead of the wave-cooperative one
+};
+Knobs& knobs();
 
 #define ICPX_HIP(expr)                                                                         \
     do {                                                                                       \

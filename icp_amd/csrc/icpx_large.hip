@@ -89,6 +89,9 @@ struct LargeIcp {
     bool feature = false;
     DevBuf f_rad, f_feat_a, f_feat_b, f_nfd;
     int* h_done = nullptr;  // pinned
+    // host time at which lg_init_kernel (which samples the device's start_clock) was enqueued: the
+    // time-limit test adds ONE host offset (converge's t0 -> this moment) to the device clock since then
+    std::chrono::steady_clock::time_point init_at{};
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1241,6 +1244,7 @@ int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double hos
     const bool fill3 = D == 3 && (lg->prm.flags & ICPX_FLAG_FILL_MATCHES);
     const int with_cost = (D == 2 || fill3) ? 1 : 0;
     const int update_cost = ((D == 2 && METHOD != ICPX_VANILLA) || match_tf || fill3) ? 1 : 0;
+    lg->init_at = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(lg_init_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->guess.as<double>(), with_cost,
                        update_cost);
     ICPX_HIP(hipGetLastError());
@@ -1311,7 +1315,7 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     if (n > kLargeMaxN) return fail(ICPX_ERR_UNSUPPORTED, "source cloud above %lld points", (long long)kLargeMaxN);
     lg->n = n;
     lg->m = m;
-    lg->groups = n <= kGroupSumMaxN && !getenv("ICPX_NO_GROUP_SUMS");
+    lg->groups = n <= kGroupSumMaxN && knobs().no_group_sums == 0;
     lg->nblk = static_cast<int>(lg->groups ? (n + 63) / 64 : (n + kBlkPts - 1) / kBlkPts);
     ICPX_TRY(lg->src.reserve(sizeof(double) * D * n));
     ICPX_TRY(lg->dst.reserve(sizeof(double) * D * m));
@@ -1403,7 +1407,11 @@ int large_iterate(LargeIcp* lg) {
 
 int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_clock::time_point t0,
                    icpx_state* out) {
-    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    // elapsed = (t0 -> enqueue of lg_init_kernel, host clock, sampled once) + (device clock since lg_init_kernel
+    // ran).  Passing a fresh host time with every enqueue would count the device time twice from the second
+    // chunk on (the host synchronises between chunks), and the limit would fire at half its value.
+    const double host_offset = std::chrono::duration<double>(lg->init_at - t0).count();
+    auto elapsed = [&]() { return host_offset > 0.0 ? host_offset : 0.0; };
     LargeDev* dev = lg->dev.as<LargeDev>();
     // large_begin already ran setup without a check: evaluate the loop's first should_terminate
     if (lg->dim == 2)

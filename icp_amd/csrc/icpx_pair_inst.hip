@@ -40,18 +40,15 @@ int launch_one(const PairBatch& pb_in, int64_t n_pairs, const PairLaunch& g, hip
         int per_cu = 0;
         ICPX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, g.threads, g.lds));
         const int64_t resident = static_cast<int64_t>(per_cu > 0 ? per_cu : 1) * g.cus;
-        const char* force = std::getenv("ICPX_SCHED");  // development override: 0 = never, 1 = always
+        const int force = knobs().sched;  // development knob ICPX_SCHED: 0 = never, 1 = always
         bool use = n_pairs > resident && n_pairs <= 16 * resident && n_pairs < (1 << 20) &&
                    !(D == 2 && METHOD == ICPX_VANILLA);
-        if (force) use = force[0] == '1' && n_pairs < (1 << 20) && !(D == 2 && METHOD == ICPX_VANILLA);
+        if (force >= 0) use = force == 1 && n_pairs < (1 << 20) && !(D == 2 && METHOD == ICPX_VANILLA);
         if (use) {
             blocks = n_pairs < resident ? n_pairs : resident;
             pb.n_pairs = static_cast<int32_t>(n_pairs);
             pb.sched_steps = 1;
-            if (const char* ss = std::getenv("ICPX_SCHED_STEPS")) {  // development override
-                const int v = std::atoi(ss);
-                if (v >= 1 && v <= 64) pb.sched_steps = v;
-            }
+            if (const int v = knobs().sched_steps) pb.sched_steps = v;  // development knob ICPX_SCHED_STEPS
             ICPX_HIP(hipMemsetAsync(pb.sched_state, 0, sizeof(int32_t) * (n_pairs + 1), stream));
             pb.sched_done = pb.sched_state + n_pairs;
         } else {

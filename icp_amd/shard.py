@@ -11,16 +11,23 @@ def shard_range(n_pairs: int, rank: int, world: int):
     return lo, hi
 
 
-def gather_states(local, n_pairs: int, rank: int, world: int):
+def gather_states(local, n_pairs: int, rank: int, world: int, counts=None):
     """All ranks receive the (n_pairs, 18) f64 table of icpx_state records.  `local` holds this
     rank's rows; shards may be ragged, so rows are padded to the largest shard for the
-    all_gather and trimmed afterwards."""
+    all_gather and trimmed afterwards.  counts: the batch is several independently sharded groups
+    of pairs (bench.py: 2D pairs, then 3D pairs) whose sizes sum to n_pairs; a rank's rows are its
+    block of every group, in group order, and so are the rows of the result (rank by rank)."""
     import torch
     import torch.distributed as dist
 
     if world == 1:
         return local
-    sizes = [shard_range(n_pairs, r, world) for r in range(world)]
+    groups = [n_pairs] if counts is None else list(counts)
+    assert sum(groups) == n_pairs
+    sizes = []
+    for r in range(world):
+        rows = sum(shard_range(g, r, world)[1] - shard_range(g, r, world)[0] for g in groups)
+        sizes.append((0, rows))
     cap = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local

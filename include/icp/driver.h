@@ -49,7 +49,7 @@ namespace icp {
                 icpx_state st{};
                 icpx_check(icpx_converge(h, source.data(), source.cols(), target.data(), target.cols(),
                     guess.matrix().data(), &c, &st));
-                static_cast<DeviceICP<Dim>*>(icp_.get())->adopt_converged(source, target, st.transform);
+                icp_->device_adopt_converged(source, target, st.transform);
                 ConvergenceState state;
                 state.cost = st.cost;
                 state.iteration_count = static_cast<size_t>(st.iteration_count);

@@ -62,6 +62,12 @@ namespace icp {
         virtual void device_sync_matches() const {}
         /** The icpx handle behind this instance, or nullptr for a host-side subclass. */
         virtual icpx_handle device_handle() const { return nullptr; }
+        /** ICPDriver::converge ran the whole loop on the device: adopt its inputs and final transform.
+         *  A subclass that returns a device_handle() overrides this (DeviceICP does). */
+        virtual void device_adopt_converged(const PointCloud& source, const PointCloud& target,
+            const double* final_transform) {
+            (void)source; (void)target; (void)final_transform;
+        }
 
         friend class ICPDriver<Dim>;
 

@@ -66,15 +66,14 @@ namespace icp {
         icpx_handle device_handle() const override { return h_; }
 
         /** ICPDriver::converge hands the whole loop to the device: keep host mirrors coherent. */
-        void adopt_converged(const PointCloud<Dim>& source, const PointCloud<Dim>& target,
-            const double* final_transform) {
+        void device_adopt_converged(const PointCloud<Dim>& source, const PointCloud<Dim>& target,
+            const double* final_transform) override {
             this->a = source;
             this->b = target;
             for (int i = 0; i < (Dim + 1) * (Dim + 1); i++) this->transform.matrix().data()[i] = final_transform[i];
             transform_stale_ = false;
             matches_stale_ = true;
         }
-        friend class ICPDriver<Dim>;
 
     public:
         ~DeviceICP() override { icpx_destroy(h_); }

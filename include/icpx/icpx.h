@@ -178,16 +178,48 @@ int icpx_converge(icpx_handle h, const double* source, int64_t n, const double* 
                   const double* guess, const icpx_criteria* criteria, icpx_state* out);
 
 /* Batched ICPDriver::converge over independent scan pairs (trajectory / loop-closure
- * workloads; no reference counterpart beyond a caller's for-loop, e.g. bench/bench.cpp:56-60).
+ * workloads; no reference counterpart beyond a caller's for-loop, e.g. bench/bench.cpp:56-60, 123).
  * Pair p uses source[source_offsets[p] .. source_offsets[p+1]) (offsets in POINTS, n_pairs+1
- * entries, HOST memory) and likewise for target.  guesses: n_pairs x (dim+1)^2 column-major, or
- * NULL for identity.  out_states: n_pairs entries (host or device memory).  All pairs run on
- * params->device; shard across devices by calling once per device with a slice. */
+ * entries, HOST memory, free to reuse when the call returns) and likewise for target.  guesses:
+ * n_pairs x (dim+1)^2 column-major, or NULL for identity.  out_states: n_pairs entries (host or
+ * device memory).  All pairs run on params->device (icpx_converge_batch_multi shards over devices).
+ * Every registered method is accepted: pairs that fit the fused kernel (vanilla / trimmed, <= 4096
+ * source points, target in LDS) run in fused launches, one workgroup per pair; the others
+ * (feature_aware, flags, larger clouds) run one after the other on the multi-kernel path.
+ * Ordering: when source, target, guesses and out_states are all DEVICE memory and every pair runs
+ * fused, the call is STREAM-ORDERED on params->stream — it returns once the work is enqueued, and
+ * out_states is valid for work enqueued on that stream afterwards (or after synchronising it).
+ * Calls on different streams of one device run concurrently.  With any host array the call
+ * returns after the results have arrived.
+ * criteria must hold max_iterations or a time limit (ICPX_ERR_INVALID otherwise): the loop runs on
+ * the device and cannot be interrupted like the reference's host loop (driver.h:43-44, 63). */
 int icpx_converge_batch(int dim, int method, const icpx_params* params, int64_t n_pairs,
                         const double* source, const int64_t* source_offsets,
                         const double* target, const int64_t* target_offsets,
                         const double* guesses, const icpx_criteria* criteria,
                         icpx_state* out_states);
+
+/* icpx_converge_batch sharded over the devices of one node: shard r of `device_count`
+ * takes the contiguous block of pairs [ceil(n_pairs*r/device_count), ceil(n_pairs*(r+1)/device_count))
+ * and runs it on devices[r] (NULL: device r) with one host thread and one stream per shard; there is no
+ * exchange between devices, every shard writes its records straight into out_states (the "gather" of the
+ * 144-byte results).  A device may be listed more than once (its shards then share it on separate
+ * streams).  source / target / guesses / out_states: host memory, or memory every listed device can
+ * reach with hipMemcpyDefault.  Returns after all shards have finished.  No reference counterpart. */
+int icpx_converge_batch_multi(int dim, int method, const icpx_params* params, int device_count,
+                              const int* devices, int64_t n_pairs,
+                              const double* source, const int64_t* source_offsets,
+                              const double* target, const int64_t* target_offsets,
+                              const double* guesses, const icpx_criteria* criteria,
+                              icpx_state* out_states);
+
+
+/* Development knobs (no reference counterpart).  The ICPX_* environment variables (ICPX_PRUNE,
+ * ICPX_FILTER, ICPX_SCHED, ICPX_SCHED_STEPS, ICPX_PRUNE_HANDLES, ICPX_NO_GROUP_SUMS, ICPX_COOP,
+ * ICPX_FUSED_SINGLE_MAX, ICPX_GEOM) are read once, when the library is first used; this call
+ * changes one afterwards (value NULL = built-in default).  Every setting computes the same
+ * results; they select between kernels.  Not thread-safe against running calls. */
+int icpx_debug_knob(const char* name, const char* value);
 
 /* Measurement helper (no counterpart in the reference): one build + one query of the uniform-grid
  * search with device-memory inputs (queries, targets must be device pointers), timed with HIP

@@ -58,6 +58,33 @@ def traces():
     return out
 
 
+class _Knobs:
+    """Development knobs of libicpx (icpx_debug_knob): the library reads the ICPX_* environment once, so
+    tests that switch kernels inside one process set the knob instead, and get the defaults back afterwards."""
+
+    def __init__(self):
+        from icp_amd import _lib
+        self._lib, self._check, self._touched = _lib.load(), _lib.check, set()
+
+    def set(self, name, value):
+        self._touched.add(name)
+        self._check(self._lib.icpx_debug_knob(name.encode(), str(value).encode()))
+
+    def reset(self, name):
+        self._check(self._lib.icpx_debug_knob(name.encode(), None))
+
+    def restore(self):
+        for name in self._touched:
+            self.reset(name)
+
+
+@pytest.fixture
+def knob():
+    k = _Knobs()
+    yield k
+    k.restore()
+
+
 BENCH_CRIT = dict(max_iterations=50, transform_tol=(0.1 * np.pi / 180, 0.01))  # bench/bench.cpp:109-113
 PLY_CRIT = dict(max_iterations=100, transform_tol=(1e-4, 1e-4))               # tests/test_ply.cpp:22-23
 TEST_CRIT = dict(max_iterations=100, transform_tol=(0.1 * np.pi / 180, 0.1))  # tests/test.cpp:87-88

@@ -120,8 +120,8 @@ def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen):
 @pytest.mark.parametrize("prune_handles", ["0", "1"])
 @pytest.mark.parametrize("method", ["vanilla", "trimmed"])
 @pytest.mark.parametrize("k", [1, 2, 3])
-def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k, prune_handles, monkeypatch):
-    monkeypatch.setenv("ICPX_PRUNE_HANDLES", prune_handles)  # "1": handles through the grid-pruned kernels
+def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k, prune_handles, knob):
+    knob.set("ICPX_PRUNE_HANDLES", prune_handles)  # "1": handles through the grid-pruned kernels
     a, b = scans[k]
     d = driver(icp, icp.ICP2, method, BENCH_CRIT)
     r = d.converge(a, b)
@@ -174,8 +174,8 @@ def test_queen_large_path(icp, ob, queen, traces, method, nn):
 
 @pytest.mark.parametrize("prune_handles", ["0", "1"])
 @pytest.mark.parametrize("dim,method", [(2, "vanilla"), (2, "trimmed"), (3, "vanilla"), (3, "trimmed")])
-def test_stepwise_begin_iterate_matches_oracle_every_iteration(icp, ob, scans, dim, method, prune_handles, monkeypatch):
-    monkeypatch.setenv("ICPX_PRUNE_HANDLES", prune_handles)  # "1": handles through the grid-pruned kernels
+def test_stepwise_begin_iterate_matches_oracle_every_iteration(icp, ob, scans, dim, method, prune_handles, knob):
+    knob.set("ICPX_PRUNE_HANDLES", prune_handles)  # "1": handles through the grid-pruned kernels
     if dim == 2:
         a, b = scans[3]
         cfg = None
@@ -209,13 +209,13 @@ def test_stepwise_begin_iterate_matches_oracle_every_iteration(icp, ob, scans, d
 
 
 @pytest.mark.parametrize("single_max", ["1e18", None])
-def test_fused_sizes_and_overlap_variants(icp, ob, monkeypatch, single_max):
+def test_fused_sizes_and_overlap_variants(icp, ob, knob, single_max):
     """Every fused-kernel geometry (queries per lane 1/2/4/8) in 2D and 3D, ragged sizes — with the
     single-pair size threshold lifted (every size in the fused kernel) and at its default (sizes above
     ~1024 x 1024 take the multi-kernel path)."""
     from icp_amd import synth
     if single_max:
-        monkeypatch.setenv("ICPX_FUSED_SINGLE_MAX", single_max)
+        knob.set("ICPX_FUSED_SINGLE_MAX", single_max)
     crit = dict(max_iterations=12, transform_tol=(1e-5, 1e-5))
     for dim, n, m in [(2, 1, 1), (2, 63, 65), (2, 200, 300), (2, 500, 400), (2, 1000, 1024), (2, 2000, 1500),
                       (2, 4096, 4096), (3, 100, 90), (3, 700, 800), (3, 1500, 1400), (3, 4096, 4096)]:
@@ -346,7 +346,7 @@ def test_large_path_sizes_and_engines(icp, ob, nn):
         assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform)
 
 
-def test_large_path_sum_layouts_agree(icp, ob, monkeypatch):
+def test_large_path_sum_layouts_agree(icp, ob, knob):
     """The multi-kernel path sums per 64-point group (n <= 2^18) or per 4096-point block (beyond, or
     ICPX_NO_GROUP_SUMS): both walk the same TREE64 tree, so a converge must not change by one bit;
     sizes around the group / block boundaries, and one cloud beyond 2^18 against the oracle."""
@@ -363,11 +363,11 @@ def test_large_path_sum_layouts_agree(icp, ob, monkeypatch):
         out = []
         for env in (None, "1"):
             if env:
-                monkeypatch.setenv("ICPX_NO_GROUP_SUMS", env)
+                knob.set("ICPX_NO_GROUP_SUMS", env)
             d = driver(icp, cls, method, crit, cfg)
             r = d.converge(s, t)
             out.append((r.iteration_count, r.transform.copy(), r.cost))
-            monkeypatch.delenv("ICPX_NO_GROUP_SUMS", raising=False)
+            knob.reset("ICPX_NO_GROUP_SUMS")
         assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2], (dim, method, n)
         ro = dev_oracle(ob, dim, method, max_distance=0.35).converge(s, t, None, ob.make_criteria(**crit))
         assert out[0][0] == ro.iteration_count and np.array_equal(out[0][1], ro.transform) and out[0][2] == ro.cost
@@ -382,8 +382,8 @@ def test_large_path_sum_layouts_agree(icp, ob, monkeypatch):
 
 
 @pytest.mark.parametrize("prune_handles", ["0", "1"])
-def test_filtered_search_adversarial_inputs(icp, ob, prune_handles, monkeypatch):
-    monkeypatch.setenv("ICPX_PRUNE_HANDLES", prune_handles)  # "1": the same inputs through the grid-pruned kernels
+def test_filtered_search_adversarial_inputs(icp, ob, prune_handles, knob):
+    knob.set("ICPX_PRUNE_HANDLES", prune_handles)  # "1": the same inputs through the grid-pruned kernels
     """The f32 candidate filter of the fused kernel must never change a result: exact ties
     (lattices, duplicated targets), clouds far from the origin (the filter works about the target's
     bounding-box centre), tiny and huge scales (f32 underflow / the >= 1e18 fall-back to the plain
@@ -680,7 +680,7 @@ def test_batch_equals_single_pairs(icp, ob):
             assert cost[p] == ro.cost or (np.isnan(cost[p]) and np.isnan(ro.cost))
 
 
-def test_batch_grid_pruned_search_adversarial(icp, ob, monkeypatch):
+def test_batch_grid_pruned_search_adversarial(icp, ob, knob):
     """icpx_converge_batch searches through a per-pair LDS grid (icpx_prune.h) that must return the
     lexicographic minimum of (d2, cloud index) whatever the geometry: exact ties and duplicates,
     degenerate extents (collinear / planar / a single repeated point), clusters, data far from the
@@ -727,9 +727,9 @@ def test_batch_grid_pruned_search_adversarial(icp, ob, monkeypatch):
             cfg = icp.Config()
             cfg.set("max_distance", 0.8)
             res = icp.converge_batch(dim, method, S, so, T, to, crit, cfg)
-            monkeypatch.setenv("ICPX_PRUNE", "0")
+            knob.set("ICPX_PRUNE", "0")
             ref = icp.converge_batch(dim, method, S, so, T, to, crit, cfg)
-            monkeypatch.delenv("ICPX_PRUNE")
+            knob.reset("ICPX_PRUNE")
             for x, y in zip(res, ref):
                 assert np.array_equal(x, y, equal_nan=True), (dim, method)
             for p, (a, b) in enumerate(cs):
@@ -741,7 +741,7 @@ def test_batch_grid_pruned_search_adversarial(icp, ob, monkeypatch):
                 assert res[0][p] == ro.cost or (np.isnan(res[0][p]) and np.isnan(ro.cost)), (dim, method, p)
 
 
-def test_batch_iteration_granular_scheduler_is_bit_identical(icp, monkeypatch):
+def test_batch_iteration_granular_scheduler_is_bit_identical(icp, knob):
     """Batches whose pairs slightly outnumber the resident workgroups run through persistent
     workgroups that hand pairs over between iterations (agent-scope release/acquire).  Forced on
     and off here: states must be bit-identical, whatever workgroup ran which iteration."""
@@ -751,9 +751,9 @@ def test_batch_iteration_granular_scheduler_is_bit_identical(icp, monkeypatch):
         s, t, off, _ = synth.config5_pairs(range(P), dim, n)
         res = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("ICPX_SCHED", mode)
+            knob.set("ICPX_SCHED", mode)
             res[mode] = icp.converge_batch(dim, method, s, off, t, off, crit)
-        monkeypatch.delenv("ICPX_SCHED")
+        knob.reset("ICPX_SCHED")
         for a, b in zip(res["0"], res["1"]):
             assert np.array_equal(a, b, equal_nan=True), (dim, method)
         assert res["0"][1].min() >= 1 and len(set(res["0"][1].tolist())) > 1  # ragged iteration counts

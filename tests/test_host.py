@@ -167,3 +167,28 @@ dist.destroy_process_group()
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "OK" in out.stdout
+
+
+def test_batch_rejects_criteria_that_never_terminate():
+    """the converge loop runs inside one kernel, so criteria under which it cannot end are an
+    argument error (checked before any device is touched, hence testable here)."""
+    import ctypes as C
+    from icp_amd import _lib
+    from icp_amd.api import make_criteria
+    lib = _lib.load()
+    pts = np.zeros((8, 2))
+    off = np.array([0, 8], dtype=np.int64)
+    st = (_lib.State * 1)()
+    for kw in (dict(), dict(stop_cost=1.0), dict(relative=1e-3, absolute=1e-3), dict(min_iterations=5, max_iterations=2)):
+        crit = make_criteria(**kw)
+        for fn in (lib.icpx_converge_batch,):
+            rc = fn(2, _lib.TRIMMED, None, 1, pts.ctypes.data, off.ctypes.data, pts.ctypes.data, off.ctypes.data, None,
+                    C.byref(crit), C.addressof(st))
+            assert rc == _lib.ERR_INVALID, kw
+        dev = (C.c_int * 1)(0)
+        rc = lib.icpx_converge_batch_multi(2, _lib.TRIMMED, None, 1, dev, 1, pts.ctypes.data, off.ctypes.data,
+                                           pts.ctypes.data, off.ctypes.data, None, C.byref(crit), C.addressof(st))
+        assert rc == _lib.ERR_INVALID, kw
+    assert b"max_iterations" in lib.icpx_last_error()
+    assert lib.icpx_debug_knob(b"ICPX_NOPE", b"1") == _lib.ERR_INVALID
+    assert lib.icpx_debug_knob(b"ICPX_SCHED", b"1") == _lib.OK and lib.icpx_debug_knob(b"ICPX_SCHED", None) == _lib.OK

@@ -40,7 +40,10 @@ for rnd in range(rounds):
     cfg = icp_amd.Config(); cfg.set("overlap_rate", ov); cfg.set("max_distance", md)
     iters = int(rng.integers(1, 6))
     crit = icp_amd.make_criteria(max_iterations=iters)
-    os.environ["ICPX_SCHED"] = str(int(rng.integers(0, 2)))
+    sched = str(int(rng.integers(0, 2)))
+    coop = str(int(rng.integers(0, 2)))
+    icp_amd._lib.check(icp_amd._lib.load().icpx_debug_knob(b"ICPX_SCHED", sched.encode()))
+    icp_amd._lib.check(icp_amd._lib.load().icpx_debug_knob(b"ICPX_COOP", coop.encode()))
     cost, it, tr = icp_amd.converge_batch(dim, method, S, so, T, to, crit, config=cfg, device=0)
     for p in range(pairs):
         o = ob.OracleICP(dim, method, overlap_rate=ov, max_distance=md, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64)
@@ -52,6 +55,6 @@ for rnd in range(rounds):
             print("MISMATCH", dict(round=rnd, pair=p, dim=dim, method=method, kind=str(kind), scale=scale, offset=offset,
                                    n=int(so[p + 1] - so[p]), m=int(to[p + 1] - to[p]), ov=ov, iters=iters), flush=True)
     print(f"round {rnd} t={time.time() - t_start:.1f}s n_total={so[-1]}: dim={dim} {method} pairs={pairs} nmax={nmax} kind={kind} scale={scale:.2e} offset={offset:.2e} "
-          f"sched={os.environ['ICPX_SCHED']} ok", flush=True)
+          f"sched={sched} coop={coop} ok", flush=True)
 print(f"{rounds} rounds, {bad} mismatches, {time.time() - t_start:.0f} s")
 sys.exit(1 if bad else 0)
