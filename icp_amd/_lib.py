@@ -60,11 +60,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("ICPX_LIB", LIB_PATH)  # development: a -DICPX_STATS build (make -C icp_amd/csrc stats)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP library first (make -C icp_amd/csrc). "
+            f"{path} is missing: build the HIP library first (make -C icp_amd/csrc). "
             "icp_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
+    if hasattr(L, "icpx_debug_stats"):
+        L.icpx_debug_stats.argtypes = [_vp, C.c_int]
     L.icpx_init.argtypes = [C.c_int]
     L.icpx_version.restype = C.c_int
     L.icpx_last_error.restype = C.c_char_p

@@ -195,12 +195,12 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
     r.prune = false;
     if (allow_prune && !(dim == 2 && method == ICPX_VANILLA) && m >= 128 && m < 65536) {
         // grid-pruned search (icpx_prune.h); development knob: ICPX_PRUNE=0
-        if (knobs().prune != 0 && pair_lds_bytes(dim, r.tcap, r.scap, false, true) <= kMaxLds) {
+        if (knobs().prune != 0 && pair_lds_bytes(dim, r.tcap, r.scap, false, true, r.threads) <= kMaxLds) {
             r.prune = true;
             r.filter = false;  // no f32 copy in LDS
         }
     }
-    r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter, r.prune);
+    r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter, r.prune, r.threads);
     if (r.lds > kMaxLds) return false;
     if (g) *g = r;
     return true;
@@ -211,6 +211,10 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     pb.lds_target_cap = g.tcap;
     pb.lds_sort_cap = g.scap;
     pb.use_filter = g.filter ? 1 : 0;
+    pb.coop = knobs().coop != 0 ? 1 : 0;
+#ifdef ICPX_PROBE
+    if (const char* pe = std::getenv("ICPX_PROBE_MASK")) pb.coop |= std::atoi(pe);
+#endif
     int dev = 0;
     ICPX_HIP(hipGetDevice(&dev));
     DeviceInfo* di = nullptr;
@@ -1100,7 +1104,7 @@ int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double
 int icpx_debug_stats(unsigned long long* out, int reset) {
     return guarded([&]() -> int {
     ICPX_HIP(hipDeviceSynchronize());
-    unsigned long long acc[16] = {0};
+    unsigned long long acc[32] = {0};
     ICPX_TRY(stats_read_d2_plain(acc, reset));
     ICPX_TRY(stats_read_d2_prune(acc, reset));
     ICPX_TRY(stats_read_d3_plain(acc, reset));

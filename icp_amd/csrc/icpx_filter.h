@@ -93,14 +93,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // development statistics (build with -DICPX_STATS; read with icpx_debug_stats):
 //   0 seeded scans (wave)  1 exact flushes (wave)  2 two-min scans (wave)  3 near-tie lanes  4 slot rescans (wave)
 #ifdef ICPX_STATS
-__device__ unsigned long long g_icpx_stats[16];
+__device__ unsigned long long g_icpx_stats[32];
 #define ICPX_STAT(slot_, amount_)                                                                    \
     do {                                                                                             \
         unsigned long long stat_v_ = (unsigned long long)(amount_);                                  \
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_icpx_stats[slot_], stat_v_);                       \
     } while (0)
+// cycle stamps of wave 0 (s_memtime): ICPX_CYC_BEGIN(); ... ICPX_CYC(slot); ... ICPX_CYC(slot2);
+#define ICPX_CYC_BEGIN() unsigned long long cyc_t0_ = __builtin_amdgcn_s_memtime()
+#define ICPX_CYC(slot_)                                                                              \
+    do {                                                                                             \
+        unsigned long long cyc_t1_ = __builtin_amdgcn_s_memtime();                                   \
+        if (threadIdx.x == 0) atomicAdd(&g_icpx_stats[slot_], cyc_t1_ - cyc_t0_);                    \
+        cyc_t0_ = cyc_t1_;                                                                           \
+    } while (0)
 #else
 #define ICPX_STAT(slot_, amount_) do { } while (0)
+#define ICPX_CYC_BEGIN() do { } while (0)
+#define ICPX_CYC(slot_) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -428,6 +428,13 @@ ICPX_DEV bool should_terminate(const icpx_criteria& c, const PairState& s, doubl
     return false;
 }
 
+// A value that is the same in every lane, moved to scalar registers (the compiler cannot prove uniformity
+// of what comes out of LDS or of a butterfly): frees the vector registers it would occupy.
+ICPX_DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+ICPX_DEV double uniform_double(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // ---- wave-level helpers -------------------------------------------------------------------
 
 // 64-lane xor butterfly sum: every lane ends with the same value; the association order is the
@@ -486,6 +493,36 @@ ICPX_DEV double wave_sum(double v) {
     v = v + dpp_xor<1>(v);
     return v;
 }
+// Transposed butterfly levels (same additions as wave_sum's, half the adds per level): given TWO values per
+// lane, lanes whose bit DIST is clear end with x[l] + x[l ^ DIST], lanes whose bit is set with y[l] + y[l ^ DIST].
+// DIST 32 / 16: ONE v_permlane*_swap per 32-bit half does the whole exchange (x's upper half / odd rows trade
+// places with y's lower half / even rows); DIST 8: each lane sends the value it does not keep through DPP.
+template <int DIST>
+ICPX_DEV double xchg_sum(double x, double y) {
+    if constexpr (DIST == 32 || DIST == 16) {
+        const unsigned xl = static_cast<unsigned>(__double2loint(x)), xh = static_cast<unsigned>(__double2hiint(x));
+        const unsigned yl = static_cast<unsigned>(__double2loint(y)), yh = static_cast<unsigned>(__double2hiint(y));
+        double a, b;
+        if constexpr (DIST == 32) {
+            auto lo = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+            auto hi = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+            a = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
+            b = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+        } else {
+            auto lo = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+            auto hi = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+            a = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
+            b = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+        }
+        return a + b;
+    } else {
+        static_assert(DIST == 8, "xchg_sum: DIST must be 32, 16 or 8");
+        const bool up = (threadIdx.x & 8) != 0;
+        const double keep = up ? y : x, send = up ? x : y;
+        return keep + dpp_xor<8>(send);
+    }
+}
+
 ICPX_DEV int wave_sum_int(int v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);

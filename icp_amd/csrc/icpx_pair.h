@@ -37,7 +37,7 @@ struct PairLaunch {
 };
 constexpr int kGsStride = 64;   // level-1 group sums per value
 constexpr int kGsValues = 10;   // up to 9 covariance terms (+ spare)
-constexpr int kBcDoubles = 48;  // broadcast area
+constexpr int kBcDoubles = 96;  // broadcast area: transform, step, flags; [48, 86): the visit's PairState (pruned kernels)
 
 struct PairBatch {
     int dim;
@@ -72,6 +72,7 @@ struct PairBatch {
     int32_t sched_steps;       // iterations per task
     // packed-f32 candidate filter in front of the exact f64 search (nn_filtered below)
     int32_t use_filter;        // the launch reserved the f32 target copy in LDS
+    int32_t coop;              // PRUNE kernels: wave-cooperative search (icpx_prune.h) instead of the per-lane walk
     int32_t* seeds;            // n_total: previous nearest neighbour by point, carried between launches / tasks; may be nullptr
     // grid-pruned search (icpx_prune.h; PRUNE kernels): per target cloud its order by grid cell
     // (pair_perm_kernel); `seeds` then holds LDS slots (that order) instead of cloud indices
@@ -107,30 +108,59 @@ ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap, int filter) {
     return v;
 }
 
-// prune (grid-pruned search, icpx_prune.h): no f32 copy; the cell start table takes its place
-inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter, bool prune = false) {
-    if (prune) return pair_lds_filter_offset(dim, tcap, scap) + sizeof(uint16_t) * kGridTable;
+// prune (grid-pruned search, icpx_prune.h): no f32 copy; the cell start table takes its place, followed by
+// the per-wave staging of the cooperative search
+inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter, bool prune = false, int threads = 0) {
+    if (prune)
+        return pair_lds_filter_offset(dim, tcap, scap) + sizeof(uint16_t) * kGridTable +
+               static_cast<size_t>(threads / 64) * coop_wave_bytes(dim);
     return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0);
 }
 
-// TREE64 sum of NV values per point.  f(k, vals) fills the NV contributions of point tid + k*T
-// (0.0 where the point does not exist or is not selected).  Every thread receives the totals.
+// TREE64 sum of NV values per point.  f(k, v) is contribution v of point tid + k*T (exactly +0.0 where the
+// point does not exist or is not selected).  Every thread receives the totals.
+// Level 1 (per group of 64 consecutive points = one wave at one slot k): the QPT slots of a value go through
+// the butterfly TOGETHER — at xor 32, 16 and 8 two slots share one exchange (xchg_sum: the lanes with the bit
+// clear carry on with one slot, the others with the other), so a lane ends the three levels with ONE slot's
+// partial, k = 4 b3 + 2 b4 + b5 (QPT 8), and the remaining levels run once per value instead of once per
+// (value, slot).  Same partners and same additions as a butterfly per (value, slot): same bits.
 template <int NV, int QPT, typename F>
 ICPX_DEV void block_sum(F&& f, int n, int T, double* gs, double (&out)[NV]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = T >> 6;
     const int G = (n + 63) >> 6;
 #pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        int g = k * W + wave;
-        if (g < G) {
-            double vals[NV];
-            f(k, vals);
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                double s = wave_sum(vals[v]);
-                if (lane == 0) gs[v * kGsStride + g] = s;
-            }
+    for (int v = 0; v < NV; v++) {
+        double s;
+        int k;  // the slot whose group sum this lane ends up with
+        if constexpr (QPT == 8) {
+            const double y0 = xchg_sum<32>(f(0, v), f(1, v)), y1 = xchg_sum<32>(f(2, v), f(3, v));
+            const double y2 = xchg_sum<32>(f(4, v), f(5, v)), y3 = xchg_sum<32>(f(6, v), f(7, v));
+            const double z0 = xchg_sum<16>(y0, y1), z1 = xchg_sum<16>(y2, y3);
+            s = xchg_sum<8>(z0, z1);
+            k = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+        } else if constexpr (QPT == 4) {
+            const double y0 = xchg_sum<32>(f(0, v), f(1, v)), y1 = xchg_sum<32>(f(2, v), f(3, v));
+            s = xchg_sum<16>(y0, y1);
+            s = s + dpp_xor<8>(s);
+            k = ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+        } else if constexpr (QPT == 2) {
+            s = xchg_sum<32>(f(0, v), f(1, v));
+            s = s + swap_xor<16>(s);
+            s = s + dpp_xor<8>(s);
+            k = (lane >> 5) & 1;
+        } else {
+            static_assert(QPT == 1, "block_sum: QPT must be 1, 2, 4 or 8");
+            s = f(0, v);
+            s = s + swap_xor<32>(s);
+            s = s + swap_xor<16>(s);
+            s = s + dpp_xor<8>(s);
+            k = 0;
         }
+        s = s + dpp_xor<4>(s);
+        s = s + dpp_xor<2>(s);
+        s = s + dpp_xor<1>(s);
+        const int g = k * W + wave;
+        if ((lane & 7) == 0 && g < G) gs[v * kGsStride + g] = s;
     }
     __syncthreads();
     if (G <= 1) {
@@ -403,25 +433,72 @@ pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst
     for (int i = tid; i < cnt; i += T) out[atomicAdd(&cursor[cell_id(i)], 1)] = static_cast<uint16_t>(i);
 }
 
-// Correspondence step of the pruned mode: every lane searches its own QPT queries, one slot at a
-// time.  pair[k]: in = seed slot (seeded), out = LDS slot of the nearest target; best[k] = its d2.
-// (Handing the queries to the lanes in Morton order was tried: the walk is no faster with coherent
-// waves, and the exchange of queries and results through memory costs more than it saves.)
+// Correspondence step of the pruned mode: the wave searches its queries one slot (64 queries) at a time.
+// pair[k]: in = seed slot (seeded), out = LDS slot of the nearest target; best[k] = its d2.
+// The slot loop is a RUNTIME loop over register vectors (the slot index is wave-uniform, so q[k] is a
+// v_movrel, not scratch memory): one copy of the search code per kernel instead of one per slot — the
+// unrolled form was several hundred KB of instructions.
+// Per-slot registers of a lane.  The slot loops that must exist once per kernel (the search) run at runtime
+// over slot 0 and ROTATE the arrays by one slot per trip (a handful of moves), so every index stays a
+// compile-time constant: no scratch memory, no register tuples for movrel-indexing.
+template <int N>
+struct SlotVec {
+    double d[N];
+    ICPX_DEV void rotate() {
+        const double t = d[0];
+#pragma unroll
+        for (int i = 0; i + 1 < N; i++) d[i] = d[i + 1];
+        d[N - 1] = t;
+    }
+};
+template <int N>
+struct SlotVecI {
+    int d[N];
+    ICPX_DEV void rotate() {
+        const int t = d[0];
+#pragma unroll
+        for (int i = 0; i + 1 < N; i++) d[i] = d[i + 1];
+        d[N - 1] = t;
+    }
+};
+
 template <int D, int QPT>
 ICPX_DEV void pruned_search(const double (&q)[QPT][D], const bool (&valid)[QPT], const bool seeded,
-                            const LdsView<D>& L, const GridView& P, const int m, double (&best)[QPT],
-                            int (&pair)[QPT]) {
+                            const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, const bool coop,
+                            const int m, double (&best)[QPT], int (&pair)[QPT]) {
+    SlotVec<QPT> qv[D], bv;
+    SlotVecI<QPT> pv;
+    int vmask = 0;
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
+#pragma unroll
+        for (int d = 0; d < D; d++) qv[d].d[k] = q[k][d];
+        pv.d[k] = pair[k];
+        bv.d[k] = 0.0;
+        vmask |= valid[k] ? (1 << k) : 0;
+    }
+#pragma unroll 1
+    for (int k = 0; k < QPT; k++) {
+        double q1[1][D];
+#pragma unroll
+        for (int d = 0; d < D; d++) q1[0][d] = qv[d].d[0];
+        const bool v = ((vmask >> k) & 1) != 0;
         double b1[1] = {0.0};
-        int s1[1] = {pair[k]};
-        if (seeded) {
-            const double (&q1)[1][D] = reinterpret_cast<const double (&)[1][D]>(q[k]);
-            seed_bound<D, 1>(q1, L, m, b1, s1);
-        }
-        nn_grid_slot<D>(q[k], valid[k], seeded, L, P, b1[0], s1[0]);
-        best[k] = valid[k] ? b1[0] : 0.0;
-        pair[k] = valid[k] ? s1[0] : 0;
+        int s1[1] = {pv.d[0]};
+        if (seeded) seed_bound<D, 1>(q1, L, m, b1, s1);
+        if (coop) nn_coop_slot<D>(q1[0], v, seeded, L, P, S, b1[0], s1[0]);
+        else nn_grid_slot<D>(q1[0], v, seeded, L, P, b1[0], s1[0]);
+        bv.d[0] = v ? b1[0] : 0.0;
+        pv.d[0] = v ? s1[0] : 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) qv[d].rotate();
+        bv.rotate();
+        pv.rotate();
+    }
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        best[k] = bv.d[k];
+        pair[k] = pv.d[k];
     }
 }
 
@@ -458,6 +535,11 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         P.tperm = pb.tperm + d0;
         P.m = m;
     }
+    // per-wave staging of the cooperative search, behind the table
+    CoopStage<D> CS = coop_carve<D>(reinterpret_cast<char*>(lds_raw) +
+                                    pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap) +
+                                    sizeof(uint16_t) * kGridTable + static_cast<size_t>(tid >> 6) * coop_wave_bytes(D));
+    const bool coop = prune && pb.coop != 0;
 
     // ---- stage the target cloud into LDS as SoA (+ f32 copy about the bounding-box centre) ----
     const int m4 = (m + 3) & ~3;
@@ -537,7 +619,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            if (prune) pruned_search<D, QPT>(q, valid, false, L, P, m, best, pair);
+            if (prune) pruned_search<D, QPT>(q, valid, false, L, P, CS, coop, m, best, pair);
             else if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
             else nn_lds<D, QPT>(q, L, m4, best, pair);
             have_seed = filter;
@@ -550,7 +632,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         }
         // ICP::calculate_cost, icp.h:149-155
         double tot[1];
-        block_sum<1, QPT>([&](int k, double (&v)[1]) { v[0] = (D == 2 && valid[k]) ? cost[k] : 0.0; },
+        block_sum<1, QPT>([&](int k, int) -> double { return (D == 2 && valid[k]) ? cost[k] : 0.0; },
                           n, T, L.gs, tot);
         state_cost = __builtin_sqrt(tot[0] / static_cast<double>(n));
         if (tid == 0) st->cost = state_cost;
@@ -621,7 +703,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
                     if (prune) {
-                        pruned_search<D, QPT>(cur, valid, have_seed, L, P, m, best, pair);
+                        pruned_search<D, QPT>(cur, valid, have_seed, L, P, CS, coop, m, best, pair);
                     } else if (have_seed) {
                         seed_bound<D, QPT>(cur, L, m, best, pair);
                         nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
@@ -664,7 +746,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
                 if (prune) {
-                    pruned_search<D, QPT>(cur, valid, have_seed, L, P, m, best, pair);
+                    pruned_search<D, QPT>(cur, valid, have_seed, L, P, CS, coop, m, best, pair);
                 } else if (have_seed) {
                     seed_bound<D, QPT>(cur, L, m, best, pair);
                     nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
@@ -691,13 +773,10 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             constexpr int NV1 = 2 * D + 1;
             double s1[NV1];
             block_sum<NV1, QPT>(
-                [&](int k, double (&v)[NV1]) {
-#pragma unroll
-                    for (int d = 0; d < D; d++) {
-                        v[d] = sel[k] ? cur[k][d] : 0.0;
-                        v[D + d] = bp[k][d];
-                    }
-                    v[2 * D] = (D == 2 && valid[k]) ? cost[k] : 0.0;
+                [&](int k, int v) -> double {
+                    if (v < D) return sel[k] ? cur[k][v] : 0.0;
+                    if (v < 2 * D) return bp[k][v - D];
+                    return (D == 2 && valid[k]) ? cost[k] : 0.0;
                 },
                 n, T, L.gs, s1);
             double ca[D], cb[D];
@@ -711,12 +790,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             // pass 2: cross-covariance N = sum (a - ca)(b - cb)^T
             double s2[D * D];
             block_sum<D * D, QPT>(
-                [&](int k, double (&v)[D * D]) {
-#pragma unroll
-                    for (int r = 0; r < D; r++)
-#pragma unroll
-                        for (int c = 0; c < D; c++)
-                            v[c * D + r] = sel[k] ? (cur[k][r] - ca[r]) * (bp[k][c] - cb[c]) : 0.0;
+                [&](int k, int v) -> double {
+                    const int r = v % D, c = v / D;
+                    return sel[k] ? (cur[k][r] - ca[r]) * (bp[k][c] - cb[c]) : 0.0;
                 },
                 n, T, L.gs, s2);
 
@@ -828,91 +904,105 @@ constexpr int pair_min_waves(int d, int qpt, int tmax) {
     return tmax > 256 ? 1 : (d == 2 ? (qpt <= 2 ? 4 : (qpt <= 4 ? 3 : 1)) : (qpt <= 4 ? ICPX_3D_SMALL_WAVES : 1));
 }
 
+template <int D, int METHOD, int QPT>
+ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps,
+                              double* lds_raw);  // icpx_pair_pruned.h
+
+template <int D, int METHOD, int QPT, bool PRUNE>
+ICPX_DEV int pair_visit(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps, double* lds_raw) {
+    if constexpr (PRUNE) return pair_body_pruned<D, METHOD, QPT>(pb, p, do_setup, max_steps, lds_raw);
+    else return pair_body<D, METHOD, QPT, false>(pb, p, do_setup, max_steps, lds_raw);
+}
+
 template <int D, int METHOD, int QPT, int TMAX, bool PRUNE>
 __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kernel(const PairBatch pb) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    if (pb.sched_state == nullptr) {
-        pair_body<D, METHOD, QPT, PRUNE>(pb, blockIdx.x, pb.do_setup, pb.max_steps, lds_raw);
-        return;
-    }
-    // ---- persistent workgroup: iteration-granular tasks ----
+    // Two ways of handing out pairs, ONE call site of the pair's code (it is large):
+    //   plain      workgroup b runs pair b from begin to end;
+    //   scheduled  persistent workgroups take iteration-granular tasks (pair, next iterations).
     // Hand-off of a pair between workgroups (possibly on different XCDs) follows the agent-scope
-    // release / acquire recipe: every wave drains its stores and meets at the barrier (end of
-    // pair_body), lane 0 releases, then publishes the state word; the taker wins the word with a
+    // release / acquire recipe: every wave drains its stores and meets at the barrier (end of the
+    // pair's visit), lane 0 releases, then publishes the state word; the taker wins the word with a
     // CAS, acquires, and only then lets the workgroup load.
     __shared__ int s_key, s_pick, s_ready;
+    const bool sched = pb.sched_state != nullptr;
     const int tid = threadIdx.x;
     const int P = pb.n_pairs;
-    const int home = static_cast<int>(static_cast<long long>(blockIdx.x) * P / gridDim.x);
+    const int home = sched ? static_cast<int>(static_cast<long long>(blockIdx.x) * P / gridDim.x) : 0;
 #ifdef ICPX_STATS
     const uint64_t stat_alive0 = wall_clock64();
 #endif
     for (int guard = 0; guard < (1 << 30); guard++) {
-        if (tid == 0) {
-            s_key = 0x7fffffff;
-            s_ready = 0;
-        }
-        __syncthreads();
-        int best = 0x7fffffff;
-        int ready = 0;
-        for (int q = tid; q < P; q += blockDim.x) {
-            int w = __hip_atomic_load(&pb.sched_state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int st = w & 3;
-            if (st <= 1) {
-                // fewest iterations first (longest expected remaining chain); among equals the pair
-                // nearest after this workgroup's home index, so that workgroups that look at the
-                // same moment go for different pairs instead of all racing for the lowest one
-                int it = w >> 2;
-                int rot = q - home;
-                rot += rot < 0 ? P : 0;
-                int key = ((it < 2047 ? it : 2047) << 20) | rot;
-                best = key < best ? key : best;
-                ready++;
+        int q = blockIdx.x, setup = pb.do_setup;
+        uint64_t task_steps = pb.max_steps;
+        if (sched) {
+            if (tid == 0) {
+                s_key = 0x7fffffff;
+                s_ready = 0;
             }
-        }
-        if (best != 0x7fffffff) {
-            atomicMin(&s_key, best);
-            atomicAdd(&s_ready, ready);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int pick = -2;  // retry
-            if (s_key != 0x7fffffff) {
-                int q = (s_key & 0xfffff) + home;
-                q -= q >= P ? P : 0;
-                int w = __hip_atomic_load(&pb.sched_state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((w & 3) <= 1 && atomicCAS(&pb.sched_state[q], w, (w & ~3) | 2) == w) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    pick = (q << 1) | ((w & 3) == 0 ? 1 : 0);  // bit 0: fresh -> run setup
+            __syncthreads();
+            int best = 0x7fffffff;
+            int ready = 0;
+            for (int c = tid; c < P; c += blockDim.x) {
+                int w = __hip_atomic_load(&pb.sched_state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int st = w & 3;
+                if (st <= 1) {
+                    // fewest iterations first (longest expected remaining chain); among equals the pair
+                    // nearest after this workgroup's home index, so that workgroups that look at the
+                    // same moment go for different pairs instead of all racing for the lowest one
+                    int it = w >> 2;
+                    int rot = c - home;
+                    rot += rot < 0 ? P : 0;
+                    int key = ((it < 2047 ? it : 2047) << 20) | rot;
+                    best = key < best ? key : best;
+                    ready++;
                 }
-            } else if (__hip_atomic_load(pb.sched_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P) {
-                pick = -1;  // everything finished
-            } else {
-                __builtin_amdgcn_s_sleep(64);
             }
-            s_pick = pick;
+            if (best != 0x7fffffff) {
+                atomicMin(&s_key, best);
+                atomicAdd(&s_ready, ready);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int pick = -2;  // retry
+                if (s_key != 0x7fffffff) {
+                    int c = (s_key & 0xfffff) + home;
+                    c -= c >= P ? P : 0;
+                    int w = __hip_atomic_load(&pb.sched_state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((w & 3) <= 1 && atomicCAS(&pb.sched_state[c], w, (w & ~3) | 2) == w) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        pick = (c << 1) | ((w & 3) == 0 ? 1 : 0);  // bit 0: fresh -> run setup
+                    }
+                } else if (__hip_atomic_load(pb.sched_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P) {
+                    pick = -1;  // everything finished
+                } else {
+                    __builtin_amdgcn_s_sleep(64);
+                }
+                s_pick = pick;
+            }
+            __syncthreads();
+            const int pick = s_pick;
+            if (pick == -1) break;
+            if (pick == -2) continue;
+            q = pick >> 1;
+            setup = pick & 1;
+            // while at least half as many pairs are waiting as there are workgroups, a task carries two iterations
+            // (half the hand-offs and restagings); in the tail it carries one, for balance
+            task_steps = static_cast<uint64_t>(pb.sched_steps) * (2 * s_ready > static_cast<int>(gridDim.x) ? 2 : 1);
         }
-        __syncthreads();
-        const int pick = s_pick;
-        if (pick == -1) break;
-        if (pick == -2) continue;
-        const int q = pick >> 1;
-        // while at least half as many pairs are waiting as there are workgroups, a task carries two iterations
-        // (half the hand-offs and restagings); in the tail it carries one, for balance
-        const uint64_t task_steps =
-            static_cast<uint64_t>(pb.sched_steps) * (2 * s_ready > static_cast<int>(gridDim.x) ? 2 : 1);
 #ifdef ICPX_STATS
         const uint64_t stat_t0 = wall_clock64();
 #endif
-        const int code = pair_body<D, METHOD, QPT, PRUNE>(pb, q, pick & 1, task_steps, lds_raw);
+        const int code = pair_visit<D, METHOD, QPT, PRUNE>(pb, q, setup, task_steps, lds_raw);
+        if (!sched) break;
 #ifdef ICPX_STATS
         if (tid == 0) {
             atomicAdd(&g_icpx_stats[5], static_cast<unsigned long long>(wall_clock64() - stat_t0));  // busy ticks
             atomicAdd(&g_icpx_stats[6], 1ULL);                                                         // tasks
         }
 #endif
-        // pair_body ended with a barrier behind every wave's stores
+        // the visit ended with a barrier behind every wave's stores
         if (tid == 0) {
             const int iters = static_cast<int>(pb.states[q].iteration_count);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -923,7 +1013,7 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kerne
         }
     }
 #ifdef ICPX_STATS
-    if (tid == 0) atomicAdd(&g_icpx_stats[7], static_cast<unsigned long long>(wall_clock64() - stat_alive0));  // alive ticks
+    if (sched && tid == 0) atomicAdd(&g_icpx_stats[7], static_cast<unsigned long long>(wall_clock64() - stat_alive0));  // alive ticks
 #endif
 }
 

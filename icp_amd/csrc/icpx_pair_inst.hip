@@ -8,6 +8,7 @@
 
 #include "icpx_host.h"
 #include "icpx_pair.h"
+#include "icpx_pair_pruned.h"
 
 #if !defined(ICPX_INST_DIM) || !defined(ICPX_INST_PRUNE)
 #error "compile with -DICPX_INST_DIM=2|3 -DICPX_INST_PRUNE=0|1"
@@ -104,13 +105,13 @@ int ICPX_INST_NAME(ICPX_INST_DIM)(const PairBatch& pb, int64_t n_pairs, const Pa
 #else
 #define ICPX_STATS_NAME(d) ICPX_STATS_NAME2(d, _plain)
 #endif
-// adds this object's counters to out[16]; optionally clears them
+// adds this object's counters to out[32]; optionally clears them
 int ICPX_STATS_NAME(ICPX_INST_DIM)(unsigned long long* out, int reset) {
-    unsigned long long v[16];
+    unsigned long long v[32];
     ICPX_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(icpx::g_icpx_stats), sizeof(v)));
-    for (int i = 0; i < 16; i++) out[i] += v[i];
+    for (int i = 0; i < 32; i++) out[i] += v[i];
     if (reset) {
-        unsigned long long z[16] = {};
+        unsigned long long z[32] = {};
         ICPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(icpx::g_icpx_stats), z, sizeof(z)));
     }
     return ICPX_OK;

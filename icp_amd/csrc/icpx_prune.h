@@ -182,6 +182,26 @@ ICPX_DEV void grid_range(const double (&q)[D], double bound, const PairGrid& g, 
     }
 }
 
+// grid_range for the cooperative search, fewer instructions: the same box or a slightly larger one.  In cell
+// units u(v) = (v - lo) * scale a target within R' of q has u(t) >= u(q) - R' * scale; cell_of's own roundings
+// move fl(u) by less than 2^-50 (|u| + 1), which the margin (1e-12 relative, 1e-9 cells absolute) covers, and
+// the clamp to [0, G - 1] is monotone.
+template <int D>
+ICPX_DEV void grid_range_cells(const double (&q)[D], double bound, const PairGrid& g, int (&c0)[D], int (&c1)[D]) {
+    const double R = __builtin_sqrt(bound) * (1.0 + 1.0 / 1125899906842624.0) + 1e-150;  // as in grid_range
+    const double gm = static_cast<double>(g.G - 1);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const double x = (q[d] - g.lo[d]) * g.scale[d];
+        const double w = (R + (__builtin_fabs(q[d]) + R) * (1.0 / 2251799813685248.0)) * g.scale[d];
+        const double pad = (__builtin_fabs(x) + w) * 1e-12 + 1e-9;
+        const double a = __builtin_fmin(__builtin_fmax(x - w - pad, 0.0), gm);  // NaN -> 0
+        const double b = __builtin_fmin(__builtin_fmax(x + w + pad, 0.0), gm);
+        c0[d] = static_cast<int>(a);
+        c1[d] = static_cast<int>(b);
+    }
+}
+
 // Nearest neighbour of one query per lane.  seeded: (best, bslot) = exact d2 and slot of some
 // target on entry.  Out: lexicographic minimum of (d2, cloud index) over all targets, as its slot.
 template <int D>
@@ -224,6 +244,393 @@ ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded
         grid_range<D>(q, best, P.g, c0, c1);
     }
     if (__any(need)) grid_walk<D>(q, need, c0, c1, L, P, best, bslot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative search (default; ICPX_COOP=0 selects the per-lane walk above).
+//
+// The per-lane walk is a pointer chase in which every lane waits for the slowest lane of its wave
+// at two levels (rows of the box, targets of a row): about 30 % of the lanes do useful work per step.
+// Here the 64 queries of a wave (one slot of every lane) are searched TOGETHER:
+//   1. every lane turns its bound into a cell box (grid_range) and reads the start / end slot of the box's
+//      rows (at most 3 x 3 rows; lanes with larger boxes keep the per-lane walk): branch-free, clamped reads;
+//   2. the candidates (query lane, target slot) of all lanes go into ONE flat list in LDS, compacted across the
+//      lanes by ballot / mbcnt, (row, position in row)-major;
+//   3. the flat list is evaluated 64 candidates at a time — every lane busy, the loads of a step independent
+//      of the step before — with the reference's f64 expression; the squared distances go to the query's
+//      accumulator by a 64-bit LDS atomic minimum (non-negative doubles order like their bit patterns);
+//   4. the candidates that attain the minimum report their slot (atomic min and max); where the two differ —
+//      an exact tie between two targets — the tied candidates compete by (cloud index, slot) through tperm.
+// The result is the lexicographic minimum of (d2, cloud index) over the targets of the box: what grid_walk
+// returns, bit for bit.  Per-wave LDS staging: CoopStage.  Wave-slots with more candidates than the list
+// holds are searched in lane groups (halves, quarters, ...).
+// ---------------------------------------------------------------------------------------------
+constexpr int kCoopCap = 512;      // candidates of one pass that fit the flat list (8 steps of 64)
+constexpr int kCoopSteps = kCoopCap / 64;
+constexpr int kCoopBlock = 2;      // steps whose loads are issued together
+
+inline __host__ __device__ size_t coop_wave_bytes(int dim) {
+    return static_cast<size_t>(64) * 8 * dim + 64 * 8 + 64 * 4 + 64 * 4 + static_cast<size_t>(kCoopCap + 64) * 4;
+}
+
+template <int D>
+struct CoopStage {
+    double* q;                  // [D][64] the wave's queries
+    unsigned long long* accd;   // [64] running minimum of d2 (bit pattern) per query
+    unsigned* acci;             // [64] lowest slot at the minimum; (cloud index << 16 | slot) after a tie
+    unsigned* accx;             // [64] highest slot at the minimum; 0xffffffff marks a tied query
+    unsigned* list;             // [kCoopCap + 64] (query lane << 16 | target slot); the last 64: per-lane dump
+};
+
+template <int D>
+ICPX_DEV CoopStage<D> coop_carve(char* base) {  // base: this wave's staging area
+    CoopStage<D> S;
+    S.q = reinterpret_cast<double*>(base);
+    S.accd = reinterpret_cast<unsigned long long*>(base + 64 * 8 * D);
+    S.acci = reinterpret_cast<unsigned*>(base + 64 * 8 * D + 64 * 8);
+    S.accx = S.acci + 64;
+    S.list = S.accx + 64;
+    return S;
+}
+
+// sum over the wave, in a scalar
+ICPX_DEV int wave_total_int(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);  // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+// inclusive prefix sum over the lanes of a wave (DPP: row scan, then the row totals)
+ICPX_DEV int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1, out-of-row lanes read 0
+    v += t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += t;
+    // v = inclusive scan inside each row of 16 lanes; add the totals of the rows before
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+}
+
+// One pass: the lanes in `grp` (their candidates fit the list: the caller has counted) put their candidates
+// into the list, the whole wave evaluates it.  rs / rl: first slot and length of the box's rows (rl = 0 for the
+// rows a lane does not have); nrows: rows any lane of the wave has.  Out, for the lanes of grp: (rb, rsl) = the
+// box's lexicographic minimum of (d2, cloud index) and its slot, (+inf, -1) for an empty box.
+template <int D, int NR>
+ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR], const int (&rl)[NR], const int nrows,
+                        const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl) {
+    const int lane = threadIdx.x & 63;
+    ICPX_CYC_BEGIN();
+#pragma unroll
+    for (int d = 0; d < D; d++) S.q[d * 64 + lane] = q[d];
+    S.accd[lane] = 0x7ff0000000000000ull;  // +inf
+    S.acci[lane] = 0xffffffffu;
+    S.accx[lane] = 0u;
+    // ---- the flat list, query-major: a lane's candidates follow those of the lanes before it ----
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < NR; r++) total += grp ? rl[r] : 0;
+    const int incl = wave_incl_scan(total);
+    const int base = __builtin_amdgcn_readlane(incl, 63);  // uniform: candidates of this pass
+    const unsigned tag = static_cast<unsigned>(lane) << 16;
+    const int dump = kCoopCap + lane;
+    int pos = incl - total;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (r % 3 < (nrows & 3) && r / 3 < (nrows >> 2)) {  // uniform: some lane of the wave has this row
+            const int len = grp ? rl[r] : 0;
+            // the first four of a row without a branch (a row rarely holds more), the rest in a loop
+#pragma unroll
+            for (int u = 0; u < 4; u++) S.list[u < len ? pos + u : dump] = tag | static_cast<unsigned>(rs[r] + u);
+            if (__any(len > 4)) {
+                for (int u = 4; __any(u < len); u++) S.list[u < len ? pos + u : dump] = tag | static_cast<unsigned>(rs[r] + u);
+            }
+            pos += len;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ICPX_CYC(19);  // list
+    if (threadIdx.x == 0) ICPX_STAT(22, base);
+    // ---- evaluate the flat list: 64 candidates per step, kCoopBlock steps per block (loads first, then arithmetic) ----
+    unsigned long long dk[kCoopSteps];
+    unsigned ent[kCoopSteps];
+#pragma unroll
+    for (int c = 0; c < kCoopSteps; c++) {
+        dk[c] = ~0ull;
+        ent[c] = tag;
+    }
+#pragma unroll
+    for (int cb = 0; cb < kCoopSteps; cb += kCoopBlock) {
+        if (cb * 64 < base) {  // uniform
+            unsigned e[kCoopBlock];
+            bool on[kCoopBlock];
+#pragma unroll
+            for (int u = 0; u < kCoopBlock; u++) {
+                const int i = (cb + u) * 64 + lane;
+                on[u] = i < base;
+                e[u] = S.list[on[u] ? i : dump];
+            }
+            double tq[kCoopBlock][D], tt[kCoopBlock][D];
+#pragma unroll
+            for (int u = 0; u < kCoopBlock; u++) {
+                e[u] = on[u] ? e[u] : tag;  // lanes past the end: slot 0 against their own query, never counted
+                const int ql = static_cast<int>(e[u] >> 16), j = static_cast<int>(e[u] & 0xffffu);
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    tq[u][d] = S.q[d * 64 + ql];
+                    tt[u][d] = L.t[d][j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kCoopBlock; u++) {
+                double df = tt[u][0] - tq[u][0];
+                double acc = df * df;
+#pragma unroll
+                for (int d = 1; d < D; d++) {
+                    df = tt[u][d] - tq[u][d];
+                    acc = acc + df * df;
+                }
+                const unsigned long long key = on[u] ? static_cast<unsigned long long>(__double_as_longlong(acc)) : ~0ull;
+                ent[cb + u] = e[u];
+                dk[cb + u] = key;
+                __hip_atomic_fetch_min(&S.accd[e[u] >> 16], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ICPX_CYC(20);  // evaluation
+    // ---- slot of the minimum: the candidates at the minimum report their slot; the others aim at their own
+    //      lane's words with values that change nothing ----
+#pragma unroll
+    for (int cb = 0; cb < kCoopSteps; cb += kCoopBlock) {
+        if (cb * 64 < base) {
+            unsigned long long mn[kCoopBlock];
+#pragma unroll
+            for (int u = 0; u < kCoopBlock; u++) mn[u] = S.accd[ent[cb + u] >> 16];
+#pragma unroll
+            for (int u = 0; u < kCoopBlock; u++) {
+                const unsigned ql = ent[cb + u] >> 16, j = ent[cb + u] & 0xffffu;
+                const bool win = dk[cb + u] != ~0ull && dk[cb + u] == mn[u];
+                const unsigned w = win ? ql : static_cast<unsigned>(lane);
+                __hip_atomic_fetch_min(&S.acci[w], win ? j : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&S.accx[w], win ? j : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool mine = grp && total > 0;
+    const bool tied = mine && S.acci[lane] != S.accx[lane];
+    if (__any(tied)) {
+        // exact ties between different targets: the candidates at the minimum compete by cloud index
+        if (tied) {
+            S.acci[lane] = 0xffffffffu;
+            S.accx[lane] = 0xffffffffu;  // marks the query as tied
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < kCoopSteps; c++) {
+            if (c * 64 < base) {
+                const unsigned ql = ent[c] >> 16, j = ent[c] & 0xffffu;
+                if (dk[c] != ~0ull && dk[c] == S.accd[ql] && S.accx[ql] == 0xffffffffu) {
+                    const unsigned key = (static_cast<unsigned>(P.tperm[j]) << 16) | j;
+                    __hip_atomic_fetch_min(&S.acci[ql], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    ICPX_CYC(21);  // resolution
+    if (grp) {
+        if (total > 0) {
+            rb = __longlong_as_double(static_cast<long long>(S.accd[lane]));
+            rsl = static_cast<int>(S.acci[lane] & 0xffffu);
+        } else {
+            rb = __builtin_inf();
+            rsl = -1;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the staging area is reused by the next pass
+}
+
+// Lexicographic minimum of (d2, cloud index) over the targets of the cell box [c0, c1] of every lane with `act`
+// whose box has at most 3 x 3 rows: (rb, rsl), (+inf, -1) for an empty box.  Returns (per lane) whether the
+// lane's box was taken; the others (`big`) are the caller's business.
+template <int D>
+ICPX_DEV bool coop_box(const double (&q)[D], const bool act, const int (&c0)[D], const int (&c1)[D],
+                       const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl) {
+    const int lane = threadIdx.x & 63;
+    const int G = P.g.G;
+    constexpr int NR = D == 3 ? 9 : 3;
+    ICPX_CYC_BEGIN();
+    const int ny = c1[1] - c0[1] + 1;
+    const int nz = D == 3 ? c1[D - 1] - c0[D - 1] + 1 : 1;
+    const bool mine = act && ny <= 3 && nz <= 3;
+    // rows the wave needs at all (uniform): boxes are 1 - 2 cells wide once the clouds are close
+    const int nyw = __any(mine && ny > 2) ? 3 : (__any(mine && ny > 1) ? 2 : 1);
+    const int nzw = D == 3 ? (__any(mine && nz > 2) ? 3 : (__any(mine && nz > 1) ? 2 : 1)) : 1;
+    const int nrows = nyw | (nzw << 2);  // handed on to coop_pass in one scalar
+    // ---- rows of the box: row r = (iy, iz) = (r % 3, r / 3), a fixed pattern.  All reads are issued; those of
+    //      rows a lane does not have land on other words of the workgroup's LDS and are discarded ----
+    const int row0 = ((D == 3 ? c0[D - 1] * G : 0) + c0[1]) * G + c0[0];
+    const int width = c1[0] - c0[0] + 1;
+    int rs[NR], re[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int iy = r % 3, iz = r / 3;  // compile-time
+        const int at = row0 + (iy + iz * G) * G;  // (iy + iz * G) * G is uniform
+        rs[r] = P.cstart[at];
+        re[r] = P.cstart[at + width];
+    }
+    int rl[NR];
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int iy = r % 3, iz = r / 3;
+        rl[r] = (mine && iy < ny && iz < nz) ? re[r] - rs[r] : 0;
+        total += rl[r];
+    }
+    const int wtot = wave_total_int(total);
+    ICPX_CYC(17);  // row bounds
+    if (threadIdx.x == 0) ICPX_STAT(16, 1);
+    if (mine) {
+        rb = __builtin_inf();
+        rsl = -1;
+    }
+    if (wtot == 0) return mine;
+    // lane groups: 1, 2, 4 ... 64 groups of consecutive lanes, so that a group's candidates fit the list
+    int shift = 6;  // lanes per group = 1 << shift
+    int gmax = wtot;
+    while (gmax > kCoopCap && shift > 0) {
+        shift--;
+        int gsum = total;
+        for (int o = 1; o < (1 << shift); o <<= 1) gsum += __shfl_xor(gsum, o);
+        gmax = 0;
+        for (int g = 0; g < 64; g += 1 << shift) gmax = max(gmax, __shfl(gsum, g));
+        gmax = __builtin_amdgcn_readfirstlane(gmax);
+    }
+    if (gmax > kCoopCap) return false;  // one query with more candidates than the list holds: nobody was taken
+    for (int g = 0; g < 64; g += 1 << shift) {
+        const bool grp = mine && (lane >> shift) == (g >> shift);
+        coop_pass<D, NR>(q, grp, rs, rl, nrows, L, P, S, rb, rsl);
+    }
+    return mine;
+}
+
+template <int D>
+ICPX_DEV bool box_inside(const int (&a0)[D], const int (&a1)[D], const int (&b0)[D], const int (&b1)[D]) {
+    bool in = true;
+#pragma unroll
+    for (int d = 0; d < D; d++) in = in && a0[d] >= b0[d] && a1[d] <= b1[d];
+    return in;
+}
+
+// The search of one slot: same contract as nn_grid_slot.  Every lane walks through stages — 0: the 2^D cells
+// nearest to the query (a first bound: any evaluated target gives a valid one), 1: the 3^D cells around it (when
+// stage 0 found nothing or left a box too large for the list), 2: the box of its bound (complete: that box holds
+// every target at most that far, the bound's own target included) — one cooperative pass per trip, lanes in
+// different stages side by side.  A seeded lane whose bound gives a small box starts at stage 2: one trip.
+template <int D>
+ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded, const LdsView<D>& L,
+                           const GridView& P, const CoopStage<D>& S, double& best, int& bslot) {
+    bool fin = P.g.bad == 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) fin = fin && (__builtin_fabs(q[d]) < 1e150);
+    if (__any(v && !fin)) {  // non-finite or huge coordinates in this wave: the per-lane path knows them
+        nn_grid_slot<D>(q, v, seeded, L, P, best, bslot);
+        return;
+    }
+    const int G = P.g.G;
+    int r0[D], r1[D];  // box of the current bound
+    int stage = 0;
+    if (seeded) {
+        grid_range_cells<D>(q, best, P.g, r0, r1);
+        bool small = r1[1] - r0[1] < 3;
+        if (D == 3) small = small && r1[D - 1] - r0[D - 1] < 3;
+        stage = small ? 2 : 0;
+    } else {
+        best = __builtin_inf();
+        bslot = -1;
+#pragma unroll
+        for (int d = 0; d < D; d++) r0[d] = r1[d] = 0;
+    }
+    if (!v) stage = 3;
+    for (int trip = 0; trip < 4 && __any(stage < 3); trip++) {
+        int c0[D], c1[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            c0[d] = r0[d];
+            c1[d] = r1[d];
+        }
+        if (__any(stage < 2)) {
+            // local blocks: the query's cell and which half of it the query is in
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                double x = (q[d] - P.g.lo[d]) * P.g.scale[d];
+                x = __builtin_fmin(__builtin_fmax(x, 0.0), static_cast<double>(G - 1));  // NaN -> 0
+                const int cq = static_cast<int>(x);
+                const bool upper = x - static_cast<double>(cq) > 0.5;
+                const int lo2 = upper ? cq : (cq > 0 ? cq - 1 : 0);
+                const int hi2 = upper ? (cq < G - 1 ? cq + 1 : G - 1) : cq;
+                const int lo3 = cq > 0 ? cq - 1 : 0, hi3 = cq < G - 1 ? cq + 1 : G - 1;
+                c0[d] = stage == 0 ? lo2 : (stage == 1 ? lo3 : r0[d]);
+                c1[d] = stage == 0 ? hi2 : (stage == 1 ? hi3 : r1[d]);
+            }
+        }
+        const bool act = stage < 3;
+        double rb = __builtin_inf();
+        int rsl = -1;
+        const bool taken = coop_box<D>(q, act, c0, c1, L, P, S, rb, rsl);
+        // boxes the list did not take (more than 3 x 3 rows, or an overfull list): the per-lane walk, final
+        // stage only (the local blocks always fit), from the lane's own candidate
+        const bool walk = act && !taken;
+        if (__any(walk)) {
+            if (threadIdx.x == 0) ICPX_STAT(23, 1);
+            ICPX_CYC_BEGIN();
+            int w0[D], w1[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                w0[d] = r0[d];
+                w1[d] = r1[d];
+            }
+            if (stage < 2) grid_range<D>(q, best, P.g, w0, w1);  // (a local block that overflowed the list)
+            grid_walk<D>(q, walk, w0, w1, L, P, best, bslot);
+            ICPX_CYC(24);  // per-lane walk of the large boxes
+        }
+        if (act && taken) {
+            if (stage == 2) {
+                best = rb;
+                bslot = rsl;
+                stage = 3;
+            } else {
+                // a local block: its minimum joins the bound; ties go to the block (it is the lexicographic minimum there)
+                const bool take = rsl >= 0 && !(rb > best);
+                best = take ? rb : best;
+                bslot = take ? rsl : bslot;
+                grid_range_cells<D>(q, best, P.g, r0, r1);  // best = +inf (nothing yet): every cell
+                bool small = r1[1] - r0[1] < 3;
+                if (D == 3) small = small && r1[D - 1] - r0[D - 1] < 3;
+                if (take && box_inside<D>(r0, r1, c0, c1)) stage = 3;      // everything that close was in the block
+                else if (small) stage = 2;
+                else stage = stage == 0 ? 1 : 2;                           // try the larger block once, then walk
+            }
+        } else if (walk) {
+            stage = 3;
+        }
+    }
 }
 
 }  // namespace icpx

@@ -14,6 +14,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The torch wheel of this image bundles its own HIP runtime (torch/lib/libamdhip64.so, ROCm 7.0) while
+    # libicpx.so links the system one (/opt/rocm, 7.2).  Both can live in one process when torch's comes up
+    # first; the other way round torch reports "No HIP GPUs are available".  Tests that use torch tensors
+    # import it lazily, so bring it up here, whatever subset of the tests runs.
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:  # no torch: the tests that need it fail on their own import
+        pass
 
 
 @pytest.fixture(scope="session")
@@ -173,3 +182,4 @@ def check_case_3d(T, iters, case):
     assert is_approx(T[:3, :3], R, re_), (name, T)
     if max_it is not None:
         assert iters <= max_it, name
+
