@@ -142,7 +142,7 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
             pv.d[0] = v ? s1[0] : 0;
             if (D == 2) {
                 costv.d[0] = v ? b1[0] : 0.0;  // trimmed.cpp:104
-            } else {
+            } else if (METHOD == ICPX_TRIMMED || pb.m_cost) {
                 const double dist = __builtin_sqrt(__builtin_sqrt(b1[0]));  // vanilla_3d.cpp:41 on kdtree.h:126
                 if (METHOD == ICPX_TRIMMED && v && dist <= pb.max_distance) selm |= 1 << k;
                 if (pb.m_cost && v) pb.m_cost[s0 + tid + k * T] = dist;  // Neighbors of the last iterate (handles)
