@@ -49,6 +49,7 @@ SYMBOLS = [
     "icpx_destroy", "icpx_begin", "icpx_iterate", "icpx_cost", "icpx_transform", "icpx_matches",
     "icpx_sizes", "icpx_debug_neighbors", "icpx_converge", "icpx_converge_batch", "icpx_nn",
     "icpx_nn_grid_profile", "icpx_converge_batch_multi", "icpx_debug_knob",
+    "icpx_converge_batch_noalloc",
 ]
 
 _lib = None

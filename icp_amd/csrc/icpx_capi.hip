@@ -843,6 +843,130 @@ int converge_batch_multi_impl(int dim, int method, const icpx_params* params, in
     return ICPX_OK;
 }
 
+// ---- the entry point that allocates nothing ------------------------------------------------------
+
+constexpr int64_t kNoAllocMaxPairs = ICPX_NOALLOC_MAX_PAIRS;
+constexpr int64_t kNoAllocMaxPoints = ICPX_NOALLOC_MAX_POINTS;
+constexpr size_t align256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+constexpr size_t kScrOff = 0;
+constexpr size_t kScrStates = kScrOff + align256(sizeof(int64_t) * 2 * (kNoAllocMaxPairs + 1));
+constexpr size_t kScrSched = kScrStates + align256(sizeof(PairState) * kNoAllocMaxPairs);
+constexpr size_t kScrCur = kScrSched + align256(sizeof(int32_t) * 2 * (kNoAllocMaxPairs + 1));
+constexpr size_t kScrSeeds = kScrCur + align256(sizeof(double) * 3 * kNoAllocMaxPoints);
+constexpr size_t kScrTperm = kScrSeeds + align256(sizeof(int32_t) * kNoAllocMaxPoints);
+constexpr size_t kScrGrids = kScrTperm + align256(sizeof(uint16_t) * kNoAllocMaxPoints);
+constexpr size_t kScrCstart = kScrGrids + align256(sizeof(PairGrid) * kNoAllocMaxPairs);
+constexpr size_t kScratchBytes = kScrCstart + align256(sizeof(uint16_t) * kGridTable * kNoAllocMaxPairs);
+
+// Scratch of icpx_converge_batch_noalloc: every GPU the library runs on holds its own copy of this array
+// (about 18 MB) until the process ends.  In host code the NAME is only a stand-in; the device address
+// comes from hipGetSymbolAddress (scratch_for_device), once per device, and only that pointer is used.
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+std::mutex g_scratch_mu;
+std::unordered_map<int, unsigned char*> g_scratch_ptr;  // per device
+std::unordered_map<int, std::mutex*> g_scratch_call_mu;
+// `dev` must be the current device
+int scratch_for_device(int dev, unsigned char** out, std::mutex** call_mu) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    auto it = g_scratch_ptr.find(dev);
+    if (it == g_scratch_ptr.end()) {
+        void* p = nullptr;
+        ICPX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(ICPX_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", dev);
+        it = g_scratch_ptr.emplace(dev, static_cast<unsigned char*>(p)).first;
+        g_scratch_call_mu.emplace(dev, new std::mutex());
+    }
+    *out = it->second;
+    if (call_mu) *call_mu = g_scratch_call_mu[dev];
+    return ICPX_OK;
+}
+
+struct FixedRuns {
+    BatchRun v[ICPX_NOALLOC_MAX_PAIRS];
+    int64_t count = 0;
+    void push_back(const BatchRun& r) { v[count++] = r; }  // plan_batch emits at most one run per pair
+};
+
+int converge_batch_noalloc_impl(int dim, int method, const icpx_params* params, int64_t n_pairs, const double* source,
+                                const int64_t* source_offsets, const double* target, const int64_t* target_offsets,
+                                const double* guesses, const icpx_criteria* criteria, icpx_state* out_states) {
+    auto t0 = std::chrono::steady_clock::now();
+    ICPX_TRY(validate_batch_args(dim, method, params, n_pairs, source, source_offsets, target, target_offsets, criteria,
+                                 out_states));
+    if (n_pairs == 0) return ICPX_OK;
+    if (method == ICPX_FEATURE_AWARE || (params && params->flags != 0))
+        return fail(ICPX_ERR_UNSUPPORTED, "icpx_converge_batch_noalloc: vanilla and trimmed without flags only");
+    if (n_pairs > kNoAllocMaxPairs)
+        return fail(ICPX_ERR_UNSUPPORTED, "icpx_converge_batch_noalloc: %lld pairs exceed the limit of %lld",
+                    (long long)n_pairs, (long long)kNoAllocMaxPairs);
+    if (source_offsets[0] != 0 || target_offsets[0] != 0)
+        return fail(ICPX_ERR_INVALID, "icpx_converge_batch_noalloc: offsets must start at 0");
+    const int64_t n_total = source_offsets[n_pairs], m_total = target_offsets[n_pairs];
+    if (n_total > kNoAllocMaxPoints || m_total > kNoAllocMaxPoints)
+        return fail(ICPX_ERR_UNSUPPORTED,
+                    "icpx_converge_batch_noalloc: %lld source / %lld target points exceed the limit of %lld per side",
+                    (long long)n_total, (long long)m_total, (long long)kNoAllocMaxPoints);
+    icpx_params prm;
+    icpx_default_params(&prm);
+    if (params) prm = *params;
+    int dev = 0;
+    ICPX_TRY(resolve_device(prm.device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DeviceInfo* di = nullptr;
+    ICPX_TRY(device_info(dev, &di));
+    hipStream_t stream = static_cast<hipStream_t>(prm.stream);
+    if ((n_total > 0 && !is_device_ptr(source)) || (m_total > 0 && !is_device_ptr(target)) ||
+        (guesses && !is_device_ptr(guesses)) || !is_device_ptr(out_states))
+        return fail(ICPX_ERR_INVALID,
+                    "icpx_converge_batch_noalloc stages nothing: source, target, guesses and out_states must be device memory");
+    BatchCall c;
+    c.dim = dim;
+    c.method = method;
+    c.prm = prm;
+    c.n_pairs = n_pairs;
+    c.d_src = source;
+    c.d_dst = target;
+    c.d_guess = guesses;
+    c.h_soff = source_offsets;
+    c.h_doff = target_offsets;
+    c.crit = *criteria;
+    c.d_out = out_states;
+    FixedRuns runs;
+    plan_batch(c, runs);
+    for (int64_t i = 0; i < runs.count; i++)
+        if (!runs.v[i].fused)
+            return fail(ICPX_ERR_UNSUPPORTED,
+                        "icpx_converge_batch_noalloc: pair %lld (%lld x %lld points) exceeds the fused kernel's limits",
+                        (long long)runs.v[i].lo, (long long)(source_offsets[runs.v[i].lo + 1] - source_offsets[runs.v[i].lo]),
+                        (long long)(target_offsets[runs.v[i].lo + 1] - target_offsets[runs.v[i].lo]));
+    unsigned char* ptr = nullptr;
+    std::mutex* call_mu = nullptr;
+    ICPX_TRY(scratch_for_device(dev, &ptr, &call_mu));
+    std::lock_guard<std::mutex> lk(*call_mu);  // host side only: overlapping calls on other streams still race on the GPU
+    BatchScratch sc;
+    sc.soff = reinterpret_cast<int64_t*>(ptr + kScrOff);
+    sc.doff = sc.soff + n_pairs + 1;
+    sc.states = reinterpret_cast<PairState*>(ptr + kScrStates);
+    sc.sched = reinterpret_cast<int32_t*>(ptr + kScrSched);
+    sc.cur = reinterpret_cast<double*>(ptr + kScrCur);
+    sc.seeds = reinterpret_cast<int32_t*>(ptr + kScrSeeds);
+    sc.tperm = reinterpret_cast<uint16_t*>(ptr + kScrTperm);
+    sc.grids = reinterpret_cast<PairGrid*>(ptr + kScrGrids);
+    sc.cstart = reinterpret_cast<uint16_t*>(ptr + kScrCstart);
+    // everything the kernels expect to start from zero is cleared by them or here: PairState, running
+    // clouds, seeds, grids and tables are written before they are read (setup / pre-pass); the scheduler
+    // words are cleared by launch_one with hipMemsetAsync
+    ICPX_HIP(hipMemcpyAsync(sc.soff, source_offsets, sizeof(int64_t) * (n_pairs + 1), hipMemcpyHostToDevice, stream));
+    ICPX_HIP(hipMemcpyAsync(sc.doff, target_offsets, sizeof(int64_t) * (n_pairs + 1), hipMemcpyHostToDevice, stream));
+    for (int64_t i = 0; i < runs.count; i++)
+        ICPX_TRY(enqueue_fused_run(c, runs.v[i].lo, runs.v[i].hi, i, runs.v[i].geom, sc, *di, stream, t0));
+    // the offset arrays are the caller's host memory: finish the copies before returning
+    ICPX_HIP(hipStreamSynchronize(stream));
+    return ICPX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -872,6 +996,8 @@ int icpx_init(int device) {
     DeviceInfo* di = nullptr;
     ICPX_TRY(device_info(dev, &di));
     ICPX_HIP(hipFree(nullptr));
+    unsigned char* scr = nullptr;
+    ICPX_TRY(scratch_for_device(dev, &scr, nullptr));  // device address of the no-alloc entry point's scratch
     return ICPX_OK;
     });
 }
@@ -1075,6 +1201,17 @@ int icpx_converge_batch_multi(int dim, int method, const icpx_params* params, in
     return guarded([&]() -> int {
         return converge_batch_multi_impl(dim, method, params, device_count, devices, n_pairs, source, source_offsets,
                                          target, target_offsets, guesses, criteria, out_states);
+    });
+}
+
+int icpx_converge_batch_noalloc(int dim, int method, const icpx_params* params, int64_t n_pairs,
+                                const double* source, const int64_t* source_offsets,
+                                const double* target, const int64_t* target_offsets,
+                                const double* guesses, const icpx_criteria* criteria,
+                                icpx_state* out_states) {
+    return guarded([&]() -> int {
+        return converge_batch_noalloc_impl(dim, method, params, n_pairs, source, source_offsets, target, target_offsets,
+                                           guesses, criteria, out_states);
     });
 }
 

@@ -213,6 +213,25 @@ int icpx_converge_batch_multi(int dim, int method, const icpx_params* params, in
                               const double* guesses, const icpx_criteria* criteria,
                               icpx_state* out_states);
 
+/* icpx_converge_batch for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arguments
+ * and results as icpx_converge_batch, but the library calls no hipMalloc / hipFree: all device memory
+ * beyond the caller's inputs and outputs (offsets, per-pair states, scheduler words, running clouds,
+ * seeds, per-pair grids) lives in one static device array of about 18 MB that every GPU the library
+ * runs on holds until the process ends.  Limits (ICPX_ERR_UNSUPPORTED beyond them): n_pairs <=
+ * ICPX_NOALLOC_MAX_PAIRS, total source points and total target points <= ICPX_NOALLOC_MAX_POINTS
+ * each, methods vanilla / trimmed without flags, every pair within the fused kernel's limits.
+ * source, target, guesses and out_states must be DEVICE memory (nothing is staged); the offsets are
+ * host memory as in icpx_converge_batch and the call returns after the stream has drained.  All
+ * calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race. */
+#define ICPX_NOALLOC_MAX_PAIRS 256
+#define ICPX_NOALLOC_MAX_POINTS 524288
+int icpx_converge_batch_noalloc(int dim, int method, const icpx_params* params, int64_t n_pairs,
+                                const double* source, const int64_t* source_offsets,
+                                const double* target, const int64_t* target_offsets,
+                                const double* guesses, const icpx_criteria* criteria,
+                                icpx_state* out_states);
 
 /* Development knobs (no reference counterpart).  The ICPX_* environment variables (ICPX_PRUNE,
  * ICPX_FILTER, ICPX_SCHED, ICPX_SCHED_STEPS, ICPX_PRUNE_HANDLES, ICPX_NO_GROUP_SUMS, ICPX_COOP,
