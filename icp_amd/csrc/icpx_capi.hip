@@ -230,17 +230,45 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     return prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream);
 }
 
+// launch of the pre-pass kernel: its dynamic LDS holds the cloud in cell order for the certificate radii; clouds
+// too large for that get no certificates (hcert stays unused: *use_cert = false)
+int launch_prepass(int dim, int64_t n_pairs, int64_t m_max, const double* d_dst, const int64_t* d_doff, uint16_t* tperm,
+                   PairGrid* grids, uint16_t* cstart, float* hcert, bool* use_cert, hipStream_t stream) {
+    static std::mutex mu;
+    static std::unordered_map<int, bool> attr_set;  // per device
+    int dev = 0;
+    ICPX_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!attr_set[dev]) {
+            ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_perm_kernel<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPairMaxLds)));
+            ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_perm_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPairMaxLds)));
+            attr_set[dev] = true;
+        }
+    }
+    size_t lds = pair_perm_lds_bytes(dim, m_max);
+    *use_cert = hcert != nullptr && lds <= kPairMaxLds;
+    if (!*use_cert) lds = pair_perm_lds_bytes(dim, 0);
+    auto pk = dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
+    hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs)), dim3(m_max >= 2048 ? 512 : 256), lds, stream, d_dst, d_doff,
+                       tperm, grids, cstart, *use_cert ? hcert : nullptr);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
 // pre-pass of the grid-pruned search (icpx_prune.h): grid, cell order and cell table of every target cloud
 int enqueue_prepass(int dim, int64_t n_pairs, int64_t m_max, int64_t m_total, const double* d_dst, const int64_t* d_doff,
-                    DevBuf& tperm, DevBuf& grids, DevBuf& cstart, hipStream_t stream) {
+                    DevBuf& tperm, DevBuf& grids, DevBuf& cstart, DevBuf& hcert, bool* cert_out, hipStream_t stream) {
     ICPX_TRY(tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
+    ICPX_TRY(hcert.reserve(sizeof(float) * (m_total > 0 ? m_total : 1)));
     ICPX_TRY(grids.reserve(sizeof(PairGrid) * n_pairs));
     ICPX_TRY(cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
-    const size_t perm_lds = 512 + 8 * static_cast<size_t>(kGridMaxCells + 4);
-    auto pk = dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
-    hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(n_pairs)), dim3(m_max >= 2048 ? 512 : 256), perm_lds, stream, d_dst,
-                       d_doff, tperm.as<uint16_t>(), grids.as<PairGrid>(), cstart.as<uint16_t>());
-    ICPX_HIP(hipGetLastError());
+    bool use_cert = false;
+    ICPX_TRY(launch_prepass(dim, n_pairs, m_max, d_dst, d_doff, tperm.as<uint16_t>(), grids.as<PairGrid>(), cstart.as<uint16_t>(),
+                            hcert.as<float>(), &use_cert, stream));
+    if (cert_out) *cert_out = use_cert;
     return ICPX_OK;
 }
 
@@ -256,7 +284,7 @@ icpx_criteria no_criteria() {
 struct Workspace {
     std::mutex mu;
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
-    DevBuf tperm, grids, cstart;  // grid-pruned search of the batch entry point
+    DevBuf tperm, grids, cstart, hcert;  // grid-pruned search of the batch entry point
     GridIndex* grid = nullptr;    // grow-only uniform-grid index of the stand-alone queries
     // pinned staging of the offset arrays, so that a stream-ordered call can return before they are consumed
     int64_t* h_off = nullptr;
@@ -313,7 +341,8 @@ struct icpx_ctx {
     bool large = false;
     PairGeom geom{};
     DevBuf src, dst, cur, off, guess, m_point, m_pair, m_cost, pair_tmp, seeds, state, out;
-    DevBuf tperm, grids, cstart;  // grid-pruned search (geom.prune)
+    DevBuf tperm, grids, cstart, hcert;  // grid-pruned search (geom.prune)
+    bool use_cert = false;
     LargeIcp* lg = nullptr;
 };
 
@@ -350,7 +379,7 @@ int upload_pair(icpx_ctx* h, const double* source, int64_t n, const double* targ
     h->m = m;
     if (h->geom.prune)
         ICPX_TRY(enqueue_prepass(D, 1, m, m, h->dst.as<double>(), h->off.as<int64_t>() + 2, h->tperm, h->grids, h->cstart,
-                                 h->stream));
+                                 h->hcert, &h->use_cert, h->stream));
     return ICPX_OK;
 }
 
@@ -379,6 +408,7 @@ void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
         pb.tperm = h->tperm.as<uint16_t>();
         pb.grids = h->grids.as<PairGrid>();
         pb.cstart = h->cstart.as<uint16_t>();
+        pb.hcert = h->use_cert ? h->hcert.as<float>() : nullptr;
     }
 }
 
@@ -488,6 +518,7 @@ struct BatchScratch {
     uint16_t* tperm;    // m_total cell order of the targets
     PairGrid* grids;    // n_pairs
     uint16_t* cstart;   // n_pairs x kGridTable
+    float* hcert;       // m_total certificate radii
 };
 
 struct BatchCall {
@@ -535,11 +566,10 @@ int enqueue_fused_run(const BatchCall& c, int64_t lo, int64_t hi, int64_t run_in
     if (c.dim == 3) pb.cur = sc.cur;
     if (geom.filter || geom.prune) pb.seeds = sc.seeds;  // the seeded search's previous neighbours travel with the pair
     if (geom.prune) {
-        const size_t perm_lds = 512 + 8 * static_cast<size_t>(kGridMaxCells + 4);
-        auto pk = c.dim == 2 ? pair_perm_kernel<2> : pair_perm_kernel<3>;
-        hipLaunchKernelGGL(pk, dim3(static_cast<unsigned>(cnt)), dim3(m_max >= 2048 ? 512 : 256), perm_lds, stream, c.d_dst,
-                           sc.doff + lo, sc.tperm, sc.grids + lo, sc.cstart + lo * kGridTable);
-        ICPX_HIP(hipGetLastError());
+        bool use_cert = false;
+        ICPX_TRY(launch_prepass(c.dim, cnt, m_max, c.d_dst, sc.doff + lo, sc.tperm, sc.grids + lo, sc.cstart + lo * kGridTable,
+                                sc.hcert, &use_cert, stream));
+        pb.hcert = use_cert ? sc.hcert : nullptr;
         pb.tperm = sc.tperm;
         pb.grids = sc.grids + lo;
         pb.cstart = sc.cstart + lo * kGridTable;
@@ -698,6 +728,7 @@ int converge_batch_impl(int dim, int method, const icpx_params* params, int64_t 
         ICPX_TRY(ws.tperm.reserve(sizeof(uint16_t) * (m_total > 0 ? m_total : 1)));
         ICPX_TRY(ws.grids.reserve(sizeof(PairGrid) * n_pairs));
         ICPX_TRY(ws.cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
+        ICPX_TRY(ws.hcert.reserve(sizeof(float) * (m_total > 0 ? m_total : 1)));
     }
     BatchScratch sc;
     sc.soff = ws.soff.as<int64_t>();
@@ -709,6 +740,7 @@ int converge_batch_impl(int dim, int method, const icpx_params* params, int64_t 
     sc.tperm = ws.tperm.as<uint16_t>();
     sc.grids = ws.grids.as<PairGrid>();
     sc.cstart = ws.cstart.as<uint16_t>();
+    sc.hcert = ws.hcert.as<float>();
 
     int64_t run_index = 0;
     for (const BatchRun& r : runs) {
@@ -856,10 +888,11 @@ constexpr size_t kScrSeeds = kScrCur + align256(sizeof(double) * 3 * kNoAllocMax
 constexpr size_t kScrTperm = kScrSeeds + align256(sizeof(int32_t) * kNoAllocMaxPoints);
 constexpr size_t kScrGrids = kScrTperm + align256(sizeof(uint16_t) * kNoAllocMaxPoints);
 constexpr size_t kScrCstart = kScrGrids + align256(sizeof(PairGrid) * kNoAllocMaxPairs);
-constexpr size_t kScratchBytes = kScrCstart + align256(sizeof(uint16_t) * kGridTable * kNoAllocMaxPairs);
+constexpr size_t kScrHcert = kScrCstart + align256(sizeof(uint16_t) * kGridTable * kNoAllocMaxPairs);
+constexpr size_t kScratchBytes = kScrHcert + align256(sizeof(float) * kNoAllocMaxPoints);
 
 // Scratch of icpx_converge_batch_noalloc: every GPU the library runs on holds its own copy of this array
-// (about 18 MB) until the process ends.  In host code the NAME is only a stand-in; the device address
+// (about 20 MB) until the process ends.  In host code the NAME is only a stand-in; the device address
 // comes from hipGetSymbolAddress (scratch_for_device), once per device, and only that pointer is used.
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
@@ -955,6 +988,7 @@ int converge_batch_noalloc_impl(int dim, int method, const icpx_params* params, 
     sc.tperm = reinterpret_cast<uint16_t*>(ptr + kScrTperm);
     sc.grids = reinterpret_cast<PairGrid*>(ptr + kScrGrids);
     sc.cstart = reinterpret_cast<uint16_t*>(ptr + kScrCstart);
+    sc.hcert = reinterpret_cast<float*>(ptr + kScrHcert);
     // everything the kernels expect to start from zero is cleared by them or here: PairState, running
     // clouds, seeds, grids and tables are written before they are read (setup / pre-pass); the scheduler
     // words are cleared by launch_one with hipMemsetAsync
@@ -1040,7 +1074,7 @@ int icpx_destroy(icpx_handle h) {
     (void)g.enter(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->src, &h->dst, &h->cur, &h->off, &h->guess, &h->m_point, &h->m_pair,
-                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart})
+                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart, &h->hcert})
         b->release();
     if (h->lg) large_destroy(h->lg);
     delete h;

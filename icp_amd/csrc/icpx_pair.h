@@ -79,6 +79,7 @@ struct PairBatch {
     const uint16_t* tperm;     // m_total: target at LDS slot j of its pair
     const PairGrid* grids;     // n_pairs: grid of every target cloud
     const uint16_t* cstart;    // n_pairs x kGridTable: cell start tables
+    const float* hcert;        // m_total: certificate radius of the target at LDS slot j of its pair (pair_perm_kernel)
 };
 
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
@@ -300,13 +301,17 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
 }
 
 // Pre-pass of the pruned search, one workgroup per target cloud of a batch: its grid (PairGrid),
-// tperm (order by cell, a counting sort) and cstart (cell start table).  Dynamic LDS: 512 + 8 *
-// (kGridMaxCells + 4) bytes.  Target order, table and grid parameters are what the search's
+// tperm (order by cell, a counting sort), cstart (cell start table) and hcert (certificate radii).  Dynamic LDS:
+// pair_perm_lds_bytes(D, largest cloud).  Target order, table and grid parameters are what the search's
 // exactness argument rests on (icpx_prune.h).
+inline size_t pair_perm_lds_bytes(int dim, int64_t m_max) {
+    return 512 + 8 * static_cast<size_t>(kGridMaxCells + 4) + sizeof(double) * dim * static_cast<size_t>(m_max > 0 ? m_max : 1);
+}
+
 template <int D>
 __global__ void __launch_bounds__(512)
 pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst_off, uint16_t* __restrict__ tperm,
-                 PairGrid* __restrict__ grids, uint16_t* __restrict__ cstart) {
+                 PairGrid* __restrict__ grids, uint16_t* __restrict__ cstart, float* __restrict__ hcert) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const int64_t o0 = dst_off[blockIdx.x];
     const int cnt = static_cast<int>(dst_off[blockIdx.x + 1] - o0);
@@ -431,6 +436,60 @@ pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst
     __syncthreads();
     // the order inside a cell is whatever the atomics give: any order is a valid permutation
     for (int i = tid; i < cnt; i += T) out[atomicAdd(&cursor[cell_id(i)], 1)] = static_cast<uint16_t>(i);
+    if (hcert == nullptr) return;
+    // ---- certificate radii (icpx_prune.h, "seed certificate"): hc[j] <= distance from the target in slot j to
+    //      every other target of the cloud.  Exact distances to the targets of the 2^D cells nearest to it, and
+    //      the distance to the faces of that block behind which there are cells (everything outside the block
+    //      is at least that far) ----
+    __syncthreads();  // tperm is complete (and visible: same compute unit); cursor[c] = end of cell c now
+    float* __restrict__ hc = hcert + o0;
+    // the cloud in cell order, SoA, in LDS (behind the histogram and the cursors): the neighbour scans read it
+    double* ts = reinterpret_cast<double*>(cursor + kGridMaxCells + 4);
+    for (int j = tid; j < cnt; j += T) {
+        const int i = out[j];
+#pragma unroll
+        for (int d = 0; d < D; d++) ts[d * cnt + j] = pts[static_cast<int64_t>(i) * D + d];
+    }
+    __syncthreads();
+    for (int j = tid; j < cnt; j += T) {
+        double t[D], h2 = __builtin_inf(), face = __builtin_inf();
+        int b0[D], b1[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            t[d] = ts[d * cnt + j];
+            double x = (t[d] - lo[d]) * scale[d];  // cell_of's own value
+            x = __builtin_fmin(__builtin_fmax(x, 0.0), static_cast<double>(G - 1));
+            const int cq = static_cast<int>(x);
+            const bool upper = x - static_cast<double>(cq) > 0.5;
+            b0[d] = upper ? cq : (cq > 0 ? cq - 1 : 0);
+            b1[d] = upper ? (cq < G - 1 ? cq + 1 : G - 1) : cq;
+            // a target in a cell beyond the block has fl(u) >= b1 + 1 (or < b0): at least this far along the axis,
+            // with 1e-9 cells (+ 1e-9 relative) against the roundings of u
+            const double slack = 1e-9 * (__builtin_fabs(x) + 1.0);
+            if (scale[d] > 0.0) {
+                if (b1[d] < G - 1) face = __builtin_fmin(face, __builtin_fmax(static_cast<double>(b1[d] + 1) - x - slack, 0.0) / scale[d]);
+                if (b0[d] > 0) face = __builtin_fmin(face, __builtin_fmax(x - static_cast<double>(b0[d]) - slack, 0.0) / scale[d]);
+            }
+        }
+        for (int cz = (D == 3 ? b0[D - 1] : 0); cz <= (D == 3 ? b1[D - 1] : 0); cz++)
+            for (int cy = b0[1]; cy <= b1[1]; cy++) {
+                const int row = (cz * G + cy) * G;
+                const int s = cursor[row + b0[0]] - hist[row + b0[0]], e = cursor[row + b1[0]];
+                for (int jj = s; jj < e; jj++) {
+                    if (jj == j) continue;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
+                        const double df = ts[d * cnt + jj] - t[d];
+                        acc = acc + df * df;
+                    }
+                    h2 = __builtin_fmin(h2, acc);
+                }
+            }
+        double h = __builtin_fmin(__builtin_sqrt(h2), face) * (1.0 - 1e-6);  // below the true value, f32 rounding included
+        if (!(h > 1e-30) || any_bad) h = 0.0;                                 // duplicates, tiny or unusable: never certify
+        hc[j] = h < 1e30 ? static_cast<float>(h) : 1e30f;
+    }
 }
 
 // Correspondence step of the pruned mode: the wave searches its queries one slot (64 queries) at a time.

@@ -123,6 +123,12 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
     auto search = [&](const bool seeded, int& selm) __attribute__((always_inline)) {
         const XfRows<D> xr = xf_rows<D>(X);
         selm = 0;
+        // seed certificate (icpx_prune.h): the radius of every slot's seed, fetched ahead of the slot loop
+        SlotVecI<QPT> hv;  // float bit patterns
+#pragma unroll
+        for (int k = 0; k < QPT; k++)
+            hv.d[k] = (seeded && pb.hcert && m > 0 && ((vmask >> k) & 1))
+                          ? __float_as_int(pb.hcert[d0 + min(max(pv.d[k], 0), m - 1)]) : 0;
 #pragma unroll 1
         for (int k = 0; k < QPT; k++) {  // slot k sits at index 0: the arrays rotate by one slot per trip
             double a1[D], q1[1][D];
@@ -137,8 +143,14 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
             double b1[1] = {0.0};
             int s1[1] = {pv.d[0]};
             if (seeded) seed_bound<D, 1>(q1, L, m, b1, s1);
-            if (coop) nn_coop_slot<D>(q1[0], v, seeded, L, P, CS, b1[0], s1[0]);
-            else nn_grid_slot<D>(q1[0], v, seeded, L, P, b1[0], s1[0]);
+            // certified: twice the distance to the seed is below the seed's distance to every other target, so no
+            // other target can be as close (seed_certified); the seed is the answer
+            const bool todo = v && !(seeded && seed_certified(b1[0], static_cast<double>(__int_as_float(hv.d[0]))));
+            if ((threadIdx.x >> 6) == 0) ICPX_STAT(25, __popcll(__ballot(v && !todo)));
+            if (__any(todo)) {
+                if (coop) nn_coop_slot<D>(q1[0], todo, seeded, L, P, CS, b1[0], s1[0]);
+                else nn_grid_slot<D>(q1[0], todo, seeded, L, P, b1[0], s1[0]);
+            }
             pv.d[0] = v ? s1[0] : 0;
             if (D == 2) {
                 costv.d[0] = v ? b1[0] : 0.0;  // trimmed.cpp:104
@@ -150,6 +162,7 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
 #pragma unroll
             for (int d = 0; d < D; d++) av[d].rotate();
             pv.rotate();
+            hv.rotate();
             if (D == 2) costv.rotate();
         }
     };

@@ -202,6 +202,14 @@ ICPX_DEV void grid_range_cells(const double (&q)[D], double bound, const PairGri
     }
 }
 
+// Seed certificate.  hc (pair_perm_kernel) is a lower bound of the distance from the seed s to every OTHER target
+// t of the cloud.  If 2.000001 * |q - s| < hc then |q - t| >= |s - t| - |q - s| > 1.0000009 |q - s| for every
+// t != s: the computed d2(q, t) exceeds the computed d2(q, s) (their roundings are 1e-15 relative) — the seed is
+// the unique nearest target and no search is needed.  hc = 0 (duplicated or degenerate targets) never certifies.
+ICPX_DEV bool seed_certified(double d2_seed, double hc) {
+    return hc > 0.0 && 2.000001 * __builtin_sqrt(d2_seed) < hc;
+}
+
 // Nearest neighbour of one query per lane.  seeded: (best, bslot) = exact d2 and slot of some
 // target on entry.  Out: lexicographic minimum of (d2, cloud index) over all targets, as its slot.
 template <int D>

@@ -217,7 +217,7 @@ int icpx_converge_batch_multi(int dim, int method, const icpx_params* params, in
  * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arguments
  * and results as icpx_converge_batch, but the library calls no hipMalloc / hipFree: all device memory
  * beyond the caller's inputs and outputs (offsets, per-pair states, scheduler words, running clouds,
- * seeds, per-pair grids) lives in one static device array of about 18 MB that every GPU the library
+ * seeds, per-pair grids) lives in one static device array of about 20 MB that every GPU the library
  * runs on holds until the process ends.  Limits (ICPX_ERR_UNSUPPORTED beyond them): n_pairs <=
  * ICPX_NOALLOC_MAX_PAIRS, total source points and total target points <= ICPX_NOALLOC_MAX_POINTS
  * each, methods vanilla / trimmed without flags, every pair within the fused kernel's limits.
