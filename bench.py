@@ -12,8 +12,8 @@ followed by the RCCL all_gather of the per-pair results when N > 1.
 Metric: NN correspondence queries/s = source points answered by nearest-neighbour steps per second,
 summed over all ranks; converged scan pairs/s is printed in the same JSON line.
 
-roofline: dominant kernel = the fused 3D pair kernel; algorithmic work = 8 flops per
-(query, target) pair evaluated ((3*Dim - 1)), measured with events on the launch stream.
+roofline: dominant kernel = the fused 3D pair kernel, timed with events on its launch stream; work =
+what the kernel executes (roofline_3d below), the brute-force count of SURVEY §8d kept as a separate figure.
 cpu_baseline: the CPU oracle in reference order (kd-tree NN, std::sort, sequential sums), one core,
 on a bounded sample of the same pairs (rank 0, N = 1 only).
 """
@@ -131,10 +131,9 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         k3 = float(np.mean(k3_ms)) if k3_ms else float("nan")
         k2 = float(np.mean(k2_ms)) if k2_ms else float("nan")
-        flops3 = float((it3 * (8.0 * N_3D * N_3D)).sum())
-        achieved = flops3 / (k3 * 1e-3) / 1e12
-        traffic = measured_traffic()
-        valu = measured_traffic("valu_instructions_per_launch")
+        alone3, alone2 = sh.launch_alone_ms(3), sh.launch_alone_ms(2)
+        roof = roofline_3d(torch, sh, it3, alone3)
+        roof["launch_ms_in_step"] = k3
         line = {
             "metric": "nn_correspondence_queries_per_s",
             "value": total_q / (elapsed / args.steps),
@@ -150,7 +149,9 @@ def main():
             "data": "synthetic",
             "converged_pairs_per_s": total_pairs / (elapsed / args.steps),
             "verified_pairs": verified,
-            "launch_ms": {"3d": k3, "2d": k2},
+            # events on each launch's own stream: inside the timed steps (the two launches share the chip, so each
+            # spans most of the step) and launched alone after the timed region
+            "launch_ms": {"3d": k3, "2d": k2, "3d_alone": alone3, "2d_alone": alone2},
             "config": {
                 "workload": "BASELINE config 5 shard per GPU: 512 2D pairs (n=m=1024, trimmed ICP2, "
                             "overlap 0.9) + 512 3D pairs (n=m=4096, vanilla ICP3), ICPDriver "
@@ -160,36 +161,10 @@ def main():
                 "mean_iterations_3d": float(it3.mean()),
                 "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
             },
-            "roofline": {
-                "bound": "valu_fp64",
-                "kernel": "pair_kernel<3,vanilla,8,512,pruned> (fused 3D converge; persistent workgroups, one or two "
-                          "pair-iterations per task; grid-pruned exact NN search, icpx_prune.h)",
-                "note": "achieved = ALGORITHMIC f64 flops (SURVEY 8d: 8 per query-target pair of every "
-                        "correspondence step, i.e. the brute-force count) / launch time.  Since r01_f the batch "
-                        "kernel reaches the same bit-exact (d2, index) result through a per-pair uniform grid in "
-                        "LDS and only evaluates the targets of the cells within each query's bound (a few per "
-                        "cent of the pairs), so the figure exceeds the VALU peak: frac > 1 says the kernel beats "
-                        "the brute-force roofline by skipping work, not that it issues f64 faster than the "
-                        "hardware can.  The brute-force kernel it replaces (ICPX_PRUNE=0) reaches frac 0.72",
-                "achieved": achieved,
-                "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP64_PEAK_TFLOPS,
-                "frac_of_unfused_peak": achieved / (FP64_PEAK_TFLOPS / 2),
-                "launch_ms": k3,
-                "flops_per_launch": flops3,
-                "traffic": traffic,
-                # executed work: wave-level VALU instructions of the launch (PMC SQ_INSTS_VALU, profiles/) x 4 issue
-                # cycles over the cycles 1024 SIMDs have in the launch at 2.4 GHz — how busy the pruned kernel
-                # keeps the vector units (it is bound by the LDS round trips of its per-lane cell walks)
-                "valu_issue_frac": None if valu is None else valu * 4.0 / (1024 * 2.4e9 * k3 * 1e-3),
-                # the other roofline of the same launch: HBM bytes (PMC, profiles/) over its duration
-                "hbm": None if traffic is None else {"achieved": traffic / (k3 * 1e-3) / 1e9, "peak": 8000.0,
-                                                     "unit": "GB/s", "frac": traffic / (k3 * 1e-3) / 1e9 / 8000.0},
-            },
+            "roofline": roof,
         }
         if not args.no_extras and world == 1:
-            line["extras"] = extras(torch, icp_amd, synth, dev, local_rank, stream)
+            line["extras"] = extras(torch, icp_amd, synth, dev, local_rank, torch.cuda.current_stream(dev).cuda_stream)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(s2, t2, off2, s3, t3, off3, args.cpu_sample)
             line["cpu_baseline_all_cores"] = cpu_baseline_threads(s2, t2, off2, s3, t3, off3, args.cpu_sample)
@@ -198,20 +173,101 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(field="hbm_bytes_per_launch_raw"):
-    """HBM bytes (or another summarized counter) per launch of the dominant kernel from the newest committed PMC passes
-    (profiles/*_counters.json, tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs of this same command).  PMC counters cannot be read from inside this process;
-    None when absent."""
+UNFUSED_F64_PEAK_TFLOPS = FP64_PEAK_TFLOPS / 2   # one f64 flop per lane per VALU f64 issue slot (no FMA pairing)
+LDS_PEAK_TBS = 256 * 256 * 2.4e9 / 1e12          # conflict-free ds_read_b64: 256 B/clk/CU x 256 CUs x 2.4 GHz
+
+
+def roofline_3d(torch, sh, it3, k3_ms):
+    """Roofline of the dominant kernel (the fused 3D pair kernel) from the work it EXECUTES.
+
+    The kernel answers every query exactly but evaluates only the targets its grid search cannot rule out, so
+    the brute-force count of SURVEY 8(d) (8 flops per query-target pair) is not what runs: it is reported as
+    `speedup_vs_bruteforce_model`, never as frac.  Executed work is counted by the same kernel compiled with
+    -DICPX_STATS (icp_amd/lib_stats, counters in icpx_prune.h / icpx_pair_pruned.h), run here once on this
+    rank's 3D batch after the timed region, its results compared bit for bit with the timed library's:
+      executed_flops = (3*Dim - 1) x evaluated candidates   vs the unfused f64 VALU ceiling (39.3 TFLOP/s)
+      lds_bytes      = staged reads and writes of the search  vs the conflict-free ds_read_b64 rate
+      lane_fraction  = evaluated candidates / lane slots issued for them
+    HBM bytes and the VALU issue share come from rocprofv3 --pmc passes (they cannot be read from inside this
+    process): `from_profile` names the committed file."""
+    import ctypes as C
+    from icp_amd import _lib, api
+    sec = k3_ms * 1e-3   # the 3D batch launched alone on its stream (pre-pass + pair kernel), HIP events
+    brute = float((it3 * (8.0 * N_3D * N_3D)).sum())
+    roof = {
+        "bound": "valu_fp64",
+        "kernel": "pair_kernel<3,vanilla,8,512,pruned> (fused 3D converge: grid-pruned exact NN search with seed "
+                  "certificates, TREE64 sums, 3x3 Kabsch, termination; persistent workgroups)",
+        "unit": "TFLOP/s",
+        "peak": UNFUSED_F64_PEAK_TFLOPS,
+        "launch_ms": k3_ms,
+        "achieved": None, "frac": None, "traffic": None,
+        "speedup_vs_bruteforce_model": brute / sec / 1e12 / FP64_PEAK_TFLOPS,
+        "bruteforce_model": "8 flops x n x m x iterations of every pair (SURVEY 8d) / launch time / 78.6 TFLOP/s "
+                            "(FMA peak): how many brute-force-roofline kernels this launch is worth; not a roofline",
+    }
+    Ls = _lib.load_variant("lib_stats") if sh.p3 else None
+    if Ls is not None and hasattr(Ls, "icpx_debug_stats"):
+        _lib.check(Ls.icpx_init(sh.device))
+        out = torch.zeros((sh.p3, 18), dtype=torch.float64, device=sh.dev)
+        buf = (C.c_ulonglong * 32)()
+        Ls.icpx_debug_stats(buf, 1)
+        api.converge_batch(3, "vanilla", sh.d_s3, sh.off3, sh.d_t3, sh.off3, sh.crit, out_states=out,
+                           device=sh.device, stream=torch.cuda.current_stream(sh.dev).cuda_stream, lib=Ls)
+        torch.cuda.synchronize(sh.dev)
+        Ls.icpx_debug_stats(buf, 0)
+        same = bool(torch.equal(out.view(torch.int64), sh.out[sh.p2:].view(torch.int64)))
+        evals, issued, passes = int(buf[26]), int(buf[27]), int(buf[28])
+        queries, certified, seeded = int(buf[29]), int(buf[30]), int(buf[31])
+        flops = 8.0 * (evals + seeded)               # every seed is one more distance evaluation
+        # LDS bytes of the search: per evaluated candidate the target (24 B) and the staged query (24 B), the list
+        # entry written and read (8 B), the 64-bit minimum (atomic + re-read, 16 B), the slot report (8 B);
+        # per cooperative pass and lane the 18 cell-table reads (2 B), the staged query and accumulators (40 B);
+        # per seed its target (24 B) and the certificate radius comes from HBM
+        lds = evals * (24 + 24 + 8 + 16 + 8) + passes * 64 * (18 * 2 + 40) + seeded * 24
+        roof.update({
+            "achieved": flops / sec / 1e12,
+            "frac": flops / sec / 1e12 / UNFUSED_F64_PEAK_TFLOPS,
+            "executed": {
+                "source": "icp_amd/lib_stats (-DICPX_STATS build of the same kernel), one launch on this shard",
+                "results_identical_to_timed_library": same,
+                "queries": queries, "queries_answered_by_certified_seed": certified,
+                "evaluated_candidates": evals, "seed_evaluations": seeded,
+                "candidates_per_searched_query": evals / max(1, queries - certified),
+                "executed_flops": flops,
+                "lane_slots_issued": issued, "lane_fraction": evals / max(1, issued),
+                "lds_bytes": lds,
+                "lds": {"achieved": lds / sec / 1e12, "peak": LDS_PEAK_TBS, "unit": "TB/s",
+                        "frac": lds / sec / 1e12 / LDS_PEAK_TBS},
+            },
+        })
+    prof = profile_counters()
+    if prof is not None:
+        name, k = prof
+        raw, dbl = k.get("hbm_bytes_per_launch_raw"), k.get("hbm_bytes_per_launch_fetch_doubled")
+        valu = k.get("SQ_INSTS_VALU_per_launch")
+        roof["from_profile"] = name
+        roof["traffic"] = dbl
+        roof["traffic_raw"] = raw
+        if dbl is not None:
+            roof["hbm"] = {"achieved": dbl / sec / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": dbl / sec / 1e9 / 8000.0}
+        if valu is not None:
+            # wave-level VALU instructions x 4 issue cycles over the cycles 1024 SIMDs have in the launch at 2.4 GHz
+            roof["valu_issue_frac"] = valu * 4.0 / (1024 * 2.4e9 * sec)
+    return roof
+
+
+def profile_counters():
+    """(file name, per-launch counters of the 3D pair kernel) from the newest committed PMC summary
+    (profiles/rNN_*_counters.json; tools/collect_profiles.sh: rocprofv3 --pmc passes over this same command)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True) + \
-            [os.path.join(ROOT, "profiles", "r01_b_traffic.json")]:
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         try:
             with open(path) as f:
                 k = json.load(f)["kernels"]
             for name, v in k.items():
-                if "pair_kernel<3, 0" in name and field in v:
-                    return v[field]
+                if "pair_kernel<3, 0" in name:
+                    return "profiles/" + os.path.basename(path), v
         except (OSError, KeyError, ValueError):
             continue
     return None

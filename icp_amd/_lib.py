@@ -59,9 +59,20 @@ _vp = C.c_void_p
 def load():
     """Load libicpx.so. Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
     global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("ICPX_LIB", LIB_PATH)  # development: a -DICPX_STATS build (make -C icp_amd/csrc stats)
+    if _lib is None:
+        # development: ICPX_LIB names another build (make -C icp_amd/csrc stats)
+        _lib = _bind(os.environ.get("ICPX_LIB", LIB_PATH))
+    return _lib
+
+
+def load_variant(libdir: str):
+    """A second, separately bound build of the library (icp_amd/<libdir>/libicpx.so), or None when it has not
+    been built: bench.py counts executed work with the -DICPX_STATS build beside the release library."""
+    path = os.path.join(_HERE, libdir, "libicpx.so")
+    return _bind(path) if os.path.exists(path) else None
+
+
+def _bind(path):
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build the HIP library first (make -C icp_amd/csrc). "
@@ -94,7 +105,6 @@ def load():
     if hasattr(L, "icpx_converge_batch_noalloc"):
         L.icpx_converge_batch_noalloc.argtypes = L.icpx_converge_batch.argtypes
     L.icpx_nn.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int, _vp]
-    _lib = L
     return L
 
 

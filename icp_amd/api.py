@@ -272,12 +272,13 @@ class ICPDriver:
 
 def converge_batch(dim, method, sources, source_offsets, targets, target_offsets, criteria,
                    config: Config | None = None, guesses=None, out_states=None, device=-1,
-                   stream=None):
+                   stream=None, lib=None):
     """icpx_converge_batch.  sources/targets: concatenated (N, dim) clouds (numpy or torch CUDA);
     offsets: int64 numpy arrays (n_pairs+1, in points).  Returns (cost, iterations, transforms)
     numpy arrays unless `out_states` (a torch CUDA uint8/float64 buffer of n_pairs*144 bytes) is
-    given, in which case results stay on the device and None is returned."""
-    lib = L.load()
+    given, in which case results stay on the device and None is returned.  `lib`: another bound build of the
+    library (L.load_variant), default the release one."""
+    lib = lib or L.load()
     config = config or Config()
     p = L.Params()
     lib.icpx_default_params(C.byref(p))

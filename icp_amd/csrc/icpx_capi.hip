@@ -61,6 +61,7 @@ bool set_knob(Knobs& k, const char* name, const char* value) {
     else if (n == "ICPX_PRUNE_HANDLES") k.prune_handles = value ? (value[0] == '1') : 0;
     else if (n == "ICPX_NO_GROUP_SUMS") k.no_group_sums = value ? 1 : 0;
     else if (n == "ICPX_COOP") k.coop = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_FUSE_PREPASS") k.fuse_prepass = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_FUSED_SINGLE_MAX") k.fused_single_max = value ? std::atof(value) : -1.0;
     else if (n == "ICPX_GEOM") {
         int q = 0, t = 0;
@@ -82,7 +83,7 @@ Knobs& knobs() {
     static Knobs k;
     static const bool from_env = [] {
         for (const char* n : {"ICPX_PRUNE", "ICPX_FILTER", "ICPX_SCHED", "ICPX_SCHED_STEPS", "ICPX_PRUNE_HANDLES",
-                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
+                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
             if (const char* v = std::getenv(n)) set_knob(k, n, v);
         return true;
     }();
@@ -566,10 +567,20 @@ int enqueue_fused_run(const BatchCall& c, int64_t lo, int64_t hi, int64_t run_in
     if (c.dim == 3) pb.cur = sc.cur;
     if (geom.filter || geom.prune) pb.seeds = sc.seeds;  // the seeded search's previous neighbours travel with the pair
     if (geom.prune) {
-        bool use_cert = false;
-        ICPX_TRY(launch_prepass(c.dim, cnt, m_max, c.d_dst, sc.doff + lo, sc.tperm, sc.grids + lo, sc.cstart + lo * kGridTable,
-                                sc.hcert, &use_cert, stream));
-        pb.hcert = use_cert ? sc.hcert : nullptr;
+        // the pre-pass of a pair's target cloud runs inside the pair kernel's setup visit when the kernel's per-wave
+        // staging area can hold its histogram (the launch then depends on nothing before it and can share the chip
+        // with another batch from its first workgroup on); as a launch of its own otherwise
+        const bool fuse = knobs().fuse_prepass != 0 &&
+                          prepare_hist_bytes(c.dim, m_max) <= static_cast<size_t>(geom.threads / 64) * coop_wave_bytes(c.dim);
+        if (fuse) {
+            pb.prepare = 1;
+            pb.hcert = sc.hcert;
+        } else {
+            bool use_cert = false;
+            ICPX_TRY(launch_prepass(c.dim, cnt, m_max, c.d_dst, sc.doff + lo, sc.tperm, sc.grids + lo, sc.cstart + lo * kGridTable,
+                                    sc.hcert, &use_cert, stream));
+            pb.hcert = use_cert ? sc.hcert : nullptr;
+        }
         pb.tperm = sc.tperm;
         pb.grids = sc.grids + lo;
         pb.cstart = sc.cstart + lo * kGridTable;

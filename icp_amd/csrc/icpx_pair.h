@@ -76,10 +76,12 @@ struct PairBatch {
     int32_t* seeds;            // n_total: previous nearest neighbour by point, carried between launches / tasks; may be nullptr
     // grid-pruned search (icpx_prune.h; PRUNE kernels): per target cloud its order by grid cell
     // (pair_perm_kernel); `seeds` then holds LDS slots (that order) instead of cloud indices
-    const uint16_t* tperm;     // m_total: target at LDS slot j of its pair
-    const PairGrid* grids;     // n_pairs: grid of every target cloud
-    const uint16_t* cstart;    // n_pairs x kGridTable: cell start tables
-    const float* hcert;        // m_total: certificate radius of the target at LDS slot j of its pair (pair_perm_kernel)
+    uint16_t* tperm;           // m_total: target at LDS slot j of its pair
+    PairGrid* grids;           // n_pairs: grid of every target cloud
+    uint16_t* cstart;          // n_pairs x kGridTable: cell start tables
+    float* hcert;              // m_total: certificate radius of the target at LDS slot j of its pair; null = none
+    int32_t prepare;           // the setup visit of a pair computes the four above itself (prepare_target_grid);
+                               // 0: pair_perm_kernel has run before this launch
 };
 
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
@@ -217,40 +219,84 @@ ICPX_DEV void bitonic_sort(uint64_t* key, uint32_t* val, int npad, int T) {
     }
 }
 
-// k-th smallest of the (key, point) pairs held QPT per thread, rank 1-based, lexicographic order:
-// MSB-first radix select with 8-bit digits over the 64 key bits (LDS histogram, wave-0 prefix
-// scan), then — only when the rank falls strictly inside a run of equal keys — over the point
-// index.  Replaces the full sort in Trimmed::iterate (trimmed.cpp:55-58): only the threshold is
-// needed to mark the kept matches.  hist: >= 264 ints of LDS.
+// AND / OR over the wave, in scalars (DPP: quads, rows, then the four row results)
+ICPX_DEV uint32_t wave_and_u32(uint32_t v) {
+    int x = static_cast<int>(v);
+    x &= __builtin_amdgcn_update_dpp(-1, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    x &= __builtin_amdgcn_update_dpp(-1, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    x &= __builtin_amdgcn_update_dpp(-1, x, 0x124, 0xf, 0xf, false);  // row_ror:4
+    x &= __builtin_amdgcn_update_dpp(-1, x, 0x128, 0xf, 0xf, false);  // row_ror:8
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(x, 0) & __builtin_amdgcn_readlane(x, 16) &
+                                 __builtin_amdgcn_readlane(x, 32) & __builtin_amdgcn_readlane(x, 48));
+}
+ICPX_DEV uint32_t wave_or_u32(uint32_t v) {
+    int x = static_cast<int>(v);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) |
+                                 __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48));
+}
+
+// The rank-th smallest (1-based) of the (key, point) pairs held QPT per thread, lexicographic order; out: its key
+// and its point, so that the pairs <= (kth, vth) are exactly the first `rank` of the sorted sequence.  Replaces
+// the full sort in Trimmed::iterate (trimmed.cpp:55-58): only the threshold is needed to mark the kept matches.
+//   1. the bits the valid keys do not share (AND / OR over the workgroup): the digits above them are skipped;
+//   2. MSB-first radix passes with 8-bit digits from the first differing bit down (LDS histogram, wave-0 scan;
+//      after the key's bits, the point's), until at most 64 pairs are left in the rank's bucket;
+//   3. those pairs go into a list and every wave ranks them directly.
+// Positive doubles of one cloud share their leading digits, and 8 bits divide ~1000 pairs into buckets of a few:
+// typically two passes.  Workgroup-wide (barriers); hist: >= 512 ints of LDS; points must be below 65536.
 template <int QPT>
 ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT], int T, int rank, int* hist,
                            uint64_t& kth, uint32_t& vth) {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
+    int* res = hist + 256;                                               // [0] digit, [1] rank inside, [2] bucket size, [4] list length
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(hist + 264);           // 64 keys
+    uint32_t* lpt = reinterpret_cast<uint32_t*>(hist + 392);            // 64 points
+    uint32_t* wred = reinterpret_cast<uint32_t*>(hist + 456);           // per wave: and_lo, and_hi, or_lo, or_hi
     bool act[QPT];
+    uint32_t alo = 0xffffffffu, ahi = 0xffffffffu, olo = 0, ohi = 0;
 #pragma unroll
-    for (int k = 0; k < QPT; k++) act[k] = valid[k];
-    uint64_t prefix = 0;
-    uint32_t vprefix = 0;
+    for (int k = 0; k < QPT; k++) {
+        act[k] = valid[k];
+        const uint32_t lo = static_cast<uint32_t>(key[k]), hi = static_cast<uint32_t>(key[k] >> 32);
+        alo &= act[k] ? lo : 0xffffffffu;
+        ahi &= act[k] ? hi : 0xffffffffu;
+        olo |= act[k] ? lo : 0u;
+        ohi |= act[k] ? hi : 0u;
+    }
+    alo = wave_and_u32(alo);
+    ahi = wave_and_u32(ahi);
+    olo = wave_or_u32(olo);
+    ohi = wave_or_u32(ohi);
+    if (lane == 0) {
+        wred[wave * 4 + 0] = alo;
+        wred[wave * 4 + 1] = ahi;
+        wred[wave * 4 + 2] = olo;
+        wred[wave * 4 + 3] = ohi;
+    }
+    for (int i = tid; i < 256; i += T) hist[i] = 0;
+    if (tid == 0) res[4] = 0;
+    __syncthreads();
+    for (int w = 0; w < W; w++) {
+        alo &= wred[w * 4 + 0];
+        ahi &= wred[w * 4 + 1];
+        olo |= wred[w * 4 + 2];
+        ohi |= wred[w * 4 + 3];
+    }
+    const uint64_t differ = (static_cast<uint64_t>(ahi ^ ohi) << 32) | (alo ^ olo);  // (no valid key: all ones; rank is 0 then)
+    // digit windows: `shift` = low bit of the window, in the key while on_key, then in the point
+    bool on_key = differ != 0;
+    int shift = on_key ? max(63 - __builtin_clzll(differ) - 7, 0) : 8;
     int remaining = rank;
-    for (int pass = 0; pass < 10; pass++) {
-        const bool on_key = pass < 8;
-        const int shift = on_key ? 56 - 8 * pass : 8 * (9 - pass);
-        for (int i = tid; i < 256; i += T) hist[i] = 0;
-        __syncthreads();
+    for (int pass = 0; pass < 12; pass++) {
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
             const uint32_t point = static_cast<uint32_t>(tid + k * T);
             const int d = on_key ? static_cast<int>((key[k] >> shift) & 255) : static_cast<int>((point >> shift) & 255);
-            // the leading digits of positive doubles of one cloud mostly coincide: one add per wave then
-            const unsigned long long am = __ballot(act[k]);
-            if (am) {
-                const int d0 = __shfl(d, __ffsll(static_cast<long long>(am)) - 1);
-                if (__all(!act[k] || d == d0)) {
-                    if (lane == 0) atomicAdd(&hist[d0], __popcll(am));
-                } else if (act[k]) {
-                    atomicAdd(&hist[d], 1);
-                }
-            }
+            if (act[k]) atomicAdd(&hist[d], 1);
         }
         __syncthreads();
         if (tid < 64) {
@@ -258,80 +304,89 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 c[u] = hist[4 * lane + u];
+                hist[4 * lane + u] = 0;  // for the next pass
                 s += c[u];
             }
-            int incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int up = __shfl_up(incl, o);
-                incl += lane >= o ? up : 0;
-            }
+            const int incl = wave_incl_scan(s);
             int excl = incl - s;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (excl < remaining && remaining <= excl + c[u]) {
-                    hist[256] = 4 * lane + u;
-                    hist[257] = remaining - excl;
-                    hist[258] = c[u];
+                    res[0] = 4 * lane + u;
+                    res[1] = remaining - excl;
+                    res[2] = c[u];
                 }
                 excl += c[u];
             }
         }
         __syncthreads();
-        const int d = hist[256];
-        remaining = hist[257];
-        const int bucket = hist[258];
+        const int d = res[0];
+        remaining = res[1];
+        const int bucket = res[2];
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
             const uint32_t point = static_cast<uint32_t>(tid + k * T);
             const int dk = on_key ? static_cast<int>((key[k] >> shift) & 255) : static_cast<int>((point >> shift) & 255);
             act[k] = act[k] && dk == d;
         }
-        if (on_key) prefix |= static_cast<uint64_t>(d) << shift;
-        else vprefix |= static_cast<uint32_t>(d) << shift;
-        if (pass == 7 && remaining == bucket) {
-            // the whole run of equal keys is kept
-            vprefix = 0xffffffffu;
-            break;
+        if (bucket <= 64) break;
+        // (points are unique: after the point's two windows the bucket holds one pair)
+        if (on_key) {
+            if (shift == 0) {
+                on_key = false;
+                shift = 8;
+            } else {
+                shift = max(shift - 8, 0);
+            }
+        } else {
+            shift = 0;
         }
     }
-    kth = prefix;
-    vth = vprefix;
+    // ---- the bucket's pairs, ranked directly ----
+#pragma unroll
+    for (int k = 0; k < QPT; k++)
+        if (act[k]) {
+            const int pos = atomicAdd(&res[4], 1);
+            if (pos < 64) {
+                lkey[pos] = key[k];
+                lpt[pos] = static_cast<uint32_t>(tid + k * T);
+            }
+        }
+    __syncthreads();
+    const int cnt = min(res[4], 64);
+    const uint64_t mk = lane < cnt ? lkey[lane] : ~0ull;
+    const uint32_t mp = lane < cnt ? lpt[lane] : 0xffffffffu;
+    int below = 0;
+    for (int j = 0; j < cnt; j++) {
+        const uint64_t kj = lkey[j];
+        const uint32_t pj = lpt[j];
+        below += (kj < mk || (kj == mk && pj < mp)) ? 1 : 0;
+    }
+    const unsigned long long hit = __ballot(lane < cnt && below == remaining - 1);
+    const int src = hit ? __ffsll(static_cast<long long>(hit)) - 1 : 0;
+    kth = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mk >> 32), src))) << 32) |
+          static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mk & 0xffffffffu), src));
+    vth = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mp), src));
     __syncthreads();  // hist may be reused by the caller
 }
 
-// Pre-pass of the pruned search, one workgroup per target cloud of a batch: its grid (PairGrid),
-// tperm (order by cell, a counting sort), cstart (cell start table) and hcert (certificate radii).  Dynamic LDS:
-// pair_perm_lds_bytes(D, largest cloud).  Target order, table and grid parameters are what the search's
-// exactness argument rests on (icpx_prune.h).
-inline size_t pair_perm_lds_bytes(int dim, int64_t m_max) {
-    return 512 + 8 * static_cast<size_t>(kGridMaxCells + 4) + sizeof(double) * dim * static_cast<size_t>(m_max > 0 ? m_max : 1);
-}
-
+// Pre-pass of the pruned search for ONE target cloud, by one workgroup: its grid (returned to every thread),
+// tperm (order by cell, a counting sort), the cell start table and the certificate radii.  Target order, table
+// and grid parameters are what the search's exactness argument rests on (icpx_prune.h).
+//   pts / cnt       the cloud (AoS, global), cnt >= 1
+//   out             tperm of the cloud (global)
+//   table           the cloud's cell start table (global, kGridTable entries); table_lds: a copy in LDS, or null
+//   hc              certificate radii by slot (global), or null: none
+//   red             64 doubles of LDS scratch;  hist: 2 * (G^D + 4) ints of LDS scratch
+//   ts / ts_stride  LDS, D rows of ts_stride doubles: receives the cloud in cell order (SoA), padded with +inf up
+//                   to pad_to; null (only when hc is null): not staged
+// Called from pair_perm_kernel (separate launch) and from the pair kernels' setup visit (icpx_pair_pruned.h), where
+// ts is the kernel's own target area.  Workgroup-wide (barriers); ends with a barrier.
 template <int D>
-__global__ void __launch_bounds__(512)
-pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst_off, uint16_t* __restrict__ tperm,
-                 PairGrid* __restrict__ grids, uint16_t* __restrict__ cstart, float* __restrict__ hcert) {
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    const int64_t o0 = dst_off[blockIdx.x];
-    const int cnt = static_cast<int>(dst_off[blockIdx.x + 1] - o0);
+ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int cnt, uint16_t* __restrict__ out,
+                                      uint16_t* __restrict__ table, uint16_t* table_lds, float* __restrict__ hc, double* red,
+                                      int* hist, double* ts, const int ts_stride, const int pad_to) {
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
-    uint16_t* __restrict__ table = cstart + static_cast<int64_t>(blockIdx.x) * kGridTable;
-    if (cnt <= 0) {
-        if (tid == 0) {
-            PairGrid g{};
-            g.G = 1;
-            grids[blockIdx.x] = g;
-        }
-        for (int c = tid; c < kGridTable; c += T) table[c] = 0;
-        return;
-    }
-    const double* __restrict__ pts = dst + o0 * D;
-    uint16_t* __restrict__ out = tperm + o0;
-    // LDS: 64 doubles of reduction scratch, then the counting sort's histogram and cursors
-    double* red = lds_raw;
-    int* hist = reinterpret_cast<int*>(red + 64);
-    int* cursor = hist + kGridMaxCells + 4;
     double lo[D], hi[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
@@ -384,18 +439,17 @@ pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst
         scale[d] = h > l ? static_cast<double>(G) / (h - l) : 0.0;
         if (!(scale[d] < 1e300)) scale[d] = 0.0;
     }
-    if (tid == 0) {
-        PairGrid g{};
-        for (int d = 0; d < D; d++) {
-            g.lo[d] = lo[d];
-            g.scale[d] = scale[d];
-        }
-        g.G = G;
-        g.bad = any_bad ? 1 : 0;
-        grids[blockIdx.x] = g;
+    PairGrid g{};
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        g.lo[d] = lo[d];
+        g.scale[d] = scale[d];
     }
+    g.G = G;
+    g.bad = any_bad ? 1 : 0;
     int ncell = 1;
     for (int d = 0; d < D; d++) ncell *= G;
+    int* cursor = hist + ncell + 4;
     // cell id, x fastest — the function the search evaluates for the queries
     auto cell_id = [&](int i) -> int {
         int c = 0;
@@ -403,7 +457,7 @@ pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst
         return c;
     };
     for (int c = tid; c <= ncell; c += T) hist[c] = 0;
-    __syncthreads();
+    __syncthreads();  // (also: every thread has read `red`)
     for (int i = tid; i < cnt; i += T) atomicAdd(&hist[cell_id(i)], 1);
     __syncthreads();
     // exclusive scan of the cell counts: per-thread chunk, wave scan, wave totals
@@ -429,34 +483,42 @@ pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst
         if (c < ncell) {
             cursor[c] = base;
             table[c] = static_cast<uint16_t>(base);
+            if (table_lds) table_lds[c] = static_cast<uint16_t>(base);
             base += hist[c];
         }
     }
-    if (tid == 0) table[ncell] = static_cast<uint16_t>(cnt);
+    if (tid == 0) {
+        table[ncell] = static_cast<uint16_t>(cnt);
+        if (table_lds) table_lds[ncell] = static_cast<uint16_t>(cnt);
+    }
     __syncthreads();
-    // the order inside a cell is whatever the atomics give: any order is a valid permutation
-    for (int i = tid; i < cnt; i += T) out[atomicAdd(&cursor[cell_id(i)], 1)] = static_cast<uint16_t>(i);
-    if (hcert == nullptr) return;
+    // the order inside a cell is whatever the atomics give: any order is a valid permutation.  The cloud goes
+    // into LDS in that order at once
+    for (int i = tid; i < cnt; i += T) {
+        const int j = atomicAdd(&cursor[cell_id(i)], 1);
+        out[j] = static_cast<uint16_t>(i);
+        if (ts) {
+#pragma unroll
+            for (int d = 0; d < D; d++) ts[d * ts_stride + j] = pts[static_cast<int64_t>(i) * D + d];
+        }
+    }
+    if (ts) {
+        for (int j = cnt + tid; j < pad_to; j += T)
+#pragma unroll
+            for (int d = 0; d < D; d++) ts[d * ts_stride + j] = __builtin_inf();
+    }
+    __syncthreads();  // cursor[c] = end of cell c now; ts complete
+    if (hc == nullptr) return g;
     // ---- certificate radii (icpx_prune.h, "seed certificate"): hc[j] <= distance from the target in slot j to
     //      every other target of the cloud.  Exact distances to the targets of the 2^D cells nearest to it, and
     //      the distance to the faces of that block behind which there are cells (everything outside the block
     //      is at least that far) ----
-    __syncthreads();  // tperm is complete (and visible: same compute unit); cursor[c] = end of cell c now
-    float* __restrict__ hc = hcert + o0;
-    // the cloud in cell order, SoA, in LDS (behind the histogram and the cursors): the neighbour scans read it
-    double* ts = reinterpret_cast<double*>(cursor + kGridMaxCells + 4);
-    for (int j = tid; j < cnt; j += T) {
-        const int i = out[j];
-#pragma unroll
-        for (int d = 0; d < D; d++) ts[d * cnt + j] = pts[static_cast<int64_t>(i) * D + d];
-    }
-    __syncthreads();
     for (int j = tid; j < cnt; j += T) {
         double t[D], h2 = __builtin_inf(), face = __builtin_inf();
         int b0[D], b1[D];
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            t[d] = ts[d * cnt + j];
+            t[d] = ts[d * ts_stride + j];
             double x = (t[d] - lo[d]) * scale[d];  // cell_of's own value
             x = __builtin_fmin(__builtin_fmax(x, 0.0), static_cast<double>(G - 1));
             const int cq = static_cast<int>(x);
@@ -480,7 +542,7 @@ pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst
                     double acc = 0.0;
 #pragma unroll
                     for (int d = 0; d < D; d++) {
-                        const double df = ts[d * cnt + jj] - t[d];
+                        const double df = ts[d * ts_stride + jj] - t[d];
                         acc = acc + df * df;
                     }
                     h2 = __builtin_fmin(h2, acc);
@@ -490,6 +552,49 @@ pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst
         if (!(h > 1e-30) || any_bad) h = 0.0;                                 // duplicates, tiny or unusable: never certify
         hc[j] = h < 1e30 ? static_cast<float>(h) : 1e30f;
     }
+    __syncthreads();  // the scratch areas may be reused
+    return g;
+}
+
+// LDS scratch of prepare_target_grid beside the staged cloud: histogram and cursors of the largest grid
+inline __host__ __device__ size_t prepare_hist_bytes(int dim, int64_t m_max) {
+    const int G = grid_cells_per_axis(dim, static_cast<int>(m_max > 0 ? (m_max < 65536 ? m_max : 65535) : 1));
+    int ncell = 1;
+    for (int d = 0; d < dim; d++) ncell *= G;
+    return 2 * sizeof(int) * static_cast<size_t>(ncell + 4);
+}
+
+// The pre-pass as a launch of its own, one workgroup per target cloud of a batch (handles; batches whose
+// workgroups cannot hold the scratch).  Dynamic LDS: pair_perm_lds_bytes(D, largest cloud; 0 = no certificates).
+inline size_t pair_perm_lds_bytes(int dim, int64_t m_max) {
+    return 512 + 8 * static_cast<size_t>(kGridMaxCells + 4) + sizeof(double) * dim * static_cast<size_t>(m_max > 0 ? m_max : 1);
+}
+
+template <int D>
+__global__ void __launch_bounds__(512)
+pair_perm_kernel(const double* __restrict__ dst, const int64_t* __restrict__ dst_off, uint16_t* __restrict__ tperm,
+                 PairGrid* __restrict__ grids, uint16_t* __restrict__ cstart, float* __restrict__ hcert) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const int64_t o0 = dst_off[blockIdx.x];
+    const int cnt = static_cast<int>(dst_off[blockIdx.x + 1] - o0);
+    const int T = blockDim.x, tid = threadIdx.x;
+    uint16_t* __restrict__ table = cstart + static_cast<int64_t>(blockIdx.x) * kGridTable;
+    if (cnt <= 0) {
+        if (tid == 0) {
+            PairGrid g{};
+            g.G = 1;
+            grids[blockIdx.x] = g;
+        }
+        for (int c = tid; c < kGridTable; c += T) table[c] = 0;
+        return;
+    }
+    // LDS: 64 doubles of reduction scratch, the counting sort's histogram and cursors, the cloud in cell order
+    double* red = lds_raw;
+    int* hist = reinterpret_cast<int*>(red + 64);
+    double* ts = hcert ? reinterpret_cast<double*>(hist + 2 * (kGridMaxCells + 4)) : nullptr;
+    const PairGrid g = prepare_target_grid<D>(dst + o0 * D, cnt, tperm + o0, table, nullptr, hcert ? hcert + o0 : nullptr, red,
+                                              hist, ts, cnt, cnt);
+    if (tid == 0) grids[blockIdx.x] = g;
 }
 
 // Correspondence step of the pruned mode: the wave searches its queries one slot (64 queries) at a time.

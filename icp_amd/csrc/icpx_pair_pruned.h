@@ -33,27 +33,48 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
     LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, false);
     PairState* ls = reinterpret_cast<PairState*>(L.bc + 48);  // this visit's copy of the state (tid 0 works on it)
     const bool empty = (n == 0 || m == 0);
+    char* const aux = reinterpret_cast<char*>(lds_raw) + pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap);
+    uint16_t* const table = reinterpret_cast<uint16_t*>(aux);                      // the pair's cell start table
+    char* const stage_base = aux + sizeof(uint16_t) * kGridTable;                  // per-wave staging of the search
+    const CoopStage<D> CS = coop_carve<D>(stage_base + static_cast<size_t>(uniform_int(tid >> 6)) * coop_wave_bytes(D));
+    const bool coop = pb.coop != 0;
+    const int m4 = (m + 3) & ~3;
     GridView P;
-    {
-        uint16_t* table = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(lds_raw) +
-                                                      pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap));
+    P.cstart = table;
+    P.tperm = pb.tperm + d0;
+    P.m = m;
+    if (do_setup && pb.prepare) {
+        // first visit: the pre-pass of this target cloud, here (no separate launch for the batch to wait for); the
+        // cloud lands in LDS in cell order on the way.  Later visits, by any workgroup, read the results back
+        if (m > 0) {
+            P.g = prepare_target_grid<D>(dst, m, pb.tperm + d0, pb.cstart + static_cast<int64_t>(p) * kGridTable, table,
+                                         pb.hcert ? pb.hcert + d0 : nullptr, L.gs, reinterpret_cast<int*>(stage_base), L.t[0],
+                                         pb.lds_target_cap, m4);
+        } else {
+            PairGrid g{};
+            g.G = 1;
+            P.g = g;
+            for (int c = tid; c < kGridTable; c += T) {
+                table[c] = 0;
+                pb.cstart[static_cast<int64_t>(p) * kGridTable + c] = 0;
+            }
+        }
+        if (tid == 0) pb.grids[p] = P.g;
+        P.g.G = uniform_int(P.g.G);
+        P.g.bad = uniform_int(P.g.bad);
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            P.g.lo[d] = uniform_double(P.g.lo[d]);
+            P.g.scale[d] = uniform_double(P.g.scale[d]);
+        }
+    } else {
         P.g = pb.grids[p];
         int ncell = P.g.G;
         for (int d = 1; d < D; d++) ncell *= P.g.G;
         for (int c = tid; c <= ncell; c += T) table[c] = pb.cstart[static_cast<int64_t>(p) * kGridTable + c];
-        P.cstart = table;
-        P.tperm = pb.tperm + d0;
-        P.m = m;
+        // ---- target cloud into LDS (SoA, in cell order) ----
+        (void)stage_targets<D>(dst, m, m4, T, L, false, P.tperm);
     }
-    const CoopStage<D> CS = coop_carve<D>(reinterpret_cast<char*>(lds_raw) +
-                                          pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap) +
-                                          sizeof(uint16_t) * kGridTable +
-                                          static_cast<size_t>(uniform_int(tid >> 6)) * coop_wave_bytes(D));
-    const bool coop = pb.coop != 0;
-
-    // ---- target cloud into LDS (SoA, in cell order) ----
-    const int m4 = (m + 3) & ~3;
-    (void)stage_targets<D>(dst, m, m4, T, L, false, P.tperm);
 
     // ---- per-thread point slots ----
     SlotVec<QPT> av[D];  // 2D: source points a; 3D: running cloud c
@@ -147,6 +168,9 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
             // other target can be as close (seed_certified); the seed is the answer
             const bool todo = v && !(seeded && seed_certified(b1[0], static_cast<double>(__int_as_float(hv.d[0]))));
             if ((threadIdx.x >> 6) == 0) ICPX_STAT(25, __popcll(__ballot(v && !todo)));
+            ICPX_STAT(29, __popcll(__ballot(v)));           // every wave: queries answered ...
+            ICPX_STAT(30, __popcll(__ballot(v && !todo)));  // ... of which by a certified seed (no search)
+            ICPX_STAT(31, __popcll(__ballot(v && seeded))); // ... seed evaluations (one distance each)
             if (__any(todo)) {
                 if (coop) nn_coop_slot<D>(q1[0], todo, seeded, L, P, CS, b1[0], s1[0]);
                 else nn_grid_slot<D>(q1[0], todo, seeded, L, P, b1[0], s1[0]);
@@ -241,6 +265,12 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
                 uint64_t kth;
                 uint32_t vth;
                 ICPX_PHASE(8);   // correspondence search
+#ifdef ICPX_PROBE
+                if (pb.coop & 128) {
+                    kth = ~0ull;
+                    vth = ~0u;
+                } else
+#endif
                 radix_select<QPT>(skeys, valid, T, k_sel, reinterpret_cast<int*>(L.gs), kth, vth);
                 ICPX_PHASE(9);   // selection
 #pragma unroll

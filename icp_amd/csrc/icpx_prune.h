@@ -120,7 +120,7 @@ ICPX_DEV void grid_walk(const double (&q)[D], bool act, const int (&c0)[D], cons
     bool fresh = true;  // the row (cy, cz) has not been opened yet
     bool done = !act;
 #ifdef ICPX_STATS
-    unsigned st_steps = 0, st_evals = 0;
+    unsigned st_steps = 0, st_evals = 0, st_real = 0, st_issued = 0;
 #endif
     while (__any(!done)) {
 #ifdef ICPX_STATS
@@ -150,6 +150,10 @@ ICPX_DEV void grid_walk(const double (&q)[D], bool act, const int (&c0)[D], cons
         const bool go = !done && j < e;
         if (__any(go)) {
             const bool two = go && j + 1 < e;
+#ifdef ICPX_STATS
+            st_real += __popcll(__ballot(go)) + __popcll(__ballot(two));
+            st_issued += 128;
+#endif
             const int ja = go ? j : 0, jb = two ? j + 1 : ja;
             grid_eval<D>(q, go, ja, L, P, best, bslot);
             grid_eval<D>(q, two, jb, L, P, best, bslot);
@@ -162,6 +166,8 @@ ICPX_DEV void grid_walk(const double (&q)[D], bool act, const int (&c0)[D], cons
         ICPX_STAT(12, st_steps);
         ICPX_STAT(1, st_evals);
     }
+    ICPX_STAT(26, st_real);    // every wave: distance evaluations of real candidates ...
+    ICPX_STAT(27, st_issued);  // ... and the lane slots issued for them
 #endif
 }
 
@@ -369,6 +375,9 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
     __builtin_amdgcn_wave_barrier();
     ICPX_CYC(19);  // list
     if (threadIdx.x == 0) ICPX_STAT(22, base);
+    ICPX_STAT(26, base);
+    ICPX_STAT(27, 64 * kCoopBlock * ((base + 64 * kCoopBlock - 1) / (64 * kCoopBlock)));
+    ICPX_STAT(28, 1);  // cooperative passes (wave level)
     // ---- evaluate the flat list: 64 candidates per step, kCoopBlock steps per block (loads first, then arithmetic) ----
     unsigned long long dk[kCoopSteps];
     unsigned ent[kCoopSteps];

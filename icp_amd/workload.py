@@ -45,14 +45,9 @@ class Config5Shard:
         cur = torch.cuda.current_stream(self.dev)
         self.st2.wait_stream(cur)
         self.st3.wait_stream(cur)
-        # the long launch first: its workgroups take a compute unit each, the 2D ones fill in beside them
-        if self.p3:
-            if timed:
-                self.ev[0].record(self.st3)
-            api.converge_batch(3, "vanilla", self.d_s3, self.off3, self.d_t3, self.off3, self.crit,
-                               out_states=self.out[self.p2:], device=self.device, stream=self.st3.cuda_stream)
-            if timed:
-                self.ev[1].record(self.st3)
+        # the 2D launch first: its pairs are latency-bound (a chain of short iterations, two workgroups per compute
+        # unit) and finish at very different times; the persistent 3D workgroups need a whole compute unit each
+        # and start on the units the 2D pairs leave, taking their tasks from the 3D launch's queue
         if self.p2:
             if timed:
                 self.ev[2].record(self.st2)
@@ -60,6 +55,13 @@ class Config5Shard:
                                out_states=self.out[:self.p2], device=self.device, stream=self.st2.cuda_stream)
             if timed:
                 self.ev[3].record(self.st2)
+        if self.p3:
+            if timed:
+                self.ev[0].record(self.st3)
+            api.converge_batch(3, "vanilla", self.d_s3, self.off3, self.d_t3, self.off3, self.crit,
+                               out_states=self.out[self.p2:], device=self.device, stream=self.st3.cuda_stream)
+            if timed:
+                self.ev[1].record(self.st3)
         cur.wait_stream(self.st2)
         cur.wait_stream(self.st3)
 
@@ -69,6 +71,29 @@ class Config5Shard:
         k3 = self.ev[0].elapsed_time(self.ev[1]) if self.p3 else 0.0
         k2 = self.ev[2].elapsed_time(self.ev[3]) if self.p2 else 0.0
         return k3, k2
+
+    def launch_alone_ms(self, dim: int, reps: int = 5) -> float:
+        """Mean duration of the 3D (or 2D) batch launched alone on its stream (HIP events on that stream): in
+        step() the two launches share the chip, so each one's events span most of the step."""
+        torch = self.torch
+        st = self.st3 if dim == 3 else self.st2
+        if not (self.p3 if dim == 3 else self.p2):
+            return 0.0
+        torch.cuda.synchronize(self.dev)
+        ms = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            if dim == 3:
+                api.converge_batch(3, "vanilla", self.d_s3, self.off3, self.d_t3, self.off3, self.crit,
+                                   out_states=self.out[self.p2:], device=self.device, stream=st.cuda_stream)
+            else:
+                api.converge_batch(2, "trimmed", self.d_s2, self.off2, self.d_t2, self.off2, self.crit,
+                                   out_states=self.out[:self.p2], device=self.device, stream=st.cuda_stream)
+            b.record(st)
+            st.synchronize()
+            ms.append(a.elapsed_time(b))
+        return float(np.mean(ms))
 
     def states(self):
         raw = self.out.cpu().numpy().reshape(-1).view(STATE_DT)
