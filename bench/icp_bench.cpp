@@ -3,9 +3,9 @@
 // For every registered ICP2 method and every ex_data scan pair it runs ICPDriver::converge a fixed
 // number of times with the reference's settings (50 iterations at most, 0.1 degree / 0.01 unit
 // transform tolerance, bench.cpp:109-113) and prints the reference's report lines in the
-// reference's order, so that existing tooling reading that report keeps working.  Two lines are
-// added per block (prefixed "+ ", which the reference never prints): NN correspondence queries/s
-// and converged pairs/s.
+// reference's order, so that existing tooling reading that report keeps working.  Lines prefixed
+// "+ " are added per block (the reference never prints them): point counts, NN correspondence
+// queries/s, converged pairs/s and the number of sqrt-tie queries (see sqrt_tie_queries).
 //
 // usage: icp_bench [data_root=. ] [invocations=10]      (reads <data_root>/ex_data/scanK/{first,second}.csv)
 #include <algorithm>
@@ -47,6 +47,31 @@ struct Settings {
     double trans_tol = 0.01;
 };
 
+// Source points whose nearest target is ambiguous under the reference's comparison: the kd-tree compares
+// sqrt(d2) (kdtree.h:140,151), so two targets with DIFFERENT d2 but bit-identical sqrt(d2) at the minimum are a
+// tie there, resolved by traversal order, while this library compares d2 (then the index).  Such a query may get
+// another partner than in the reference; counted at the identity guess, the
+// correspondence step setup() runs.
+std::size_t sqrt_tie_queries(const icp::PointCloud2& source, const icp::PointCloud2& target) {
+    std::size_t ties = 0;
+    for (icp::Index i = 0; i < source.cols(); i++) {
+        double best = INFINITY;
+        for (icp::Index j = 0; j < target.cols(); j++) {
+            const double dx = target(0, j) - source(0, i), dy = target(1, j) - source(1, i);
+            best = std::min(best, dx * dx + dy * dy);
+        }
+        const double root = std::sqrt(best);
+        bool tie = false;
+        for (icp::Index j = 0; j < target.cols(); j++) {
+            const double dx = target(0, j) - source(0, i), dy = target(1, j) - source(1, i);
+            const double d2 = dx * dx + dy * dy;
+            tie = tie || (d2 != best && std::sqrt(d2) == root);
+        }
+        ties += tie ? 1 : 0;
+    }
+    return ties;
+}
+
 void report(const std::string& method, unsigned scan, const Settings& s) {
     const std::string dir = s.root + "/ex_data/scan" + std::to_string(scan);
     const icp::PointCloud2 source = parse_lidar_scan(dir + "/first.csv");
@@ -86,7 +111,8 @@ void report(const std::string& method, unsigned scan, const Settings& s) {
     const double nn_steps = it.total + static_cast<double>(s.invocations);
     std::cout << "+ Source / target points: " << source.cols() << " / " << target.cols() << "\n"
               << "+ NN correspondence queries/s: " << nn_steps * static_cast<double>(source.cols()) / seconds << "\n"
-              << "+ Converged pairs/s: " << static_cast<double>(s.invocations) / seconds << "\n";
+              << "+ Converged pairs/s: " << static_cast<double>(s.invocations) / seconds << "\n"
+              << "+ sqrt-tie queries at the first correspondence step: " << sqrt_tie_queries(source, target) << "\n";
 }
 
 }  // namespace

@@ -1064,8 +1064,13 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 // Small geometries are asked for 3-4 waves per SIMD (<= 168 / 128 VGPRs): their serial sections
 // (radix select, single-lane SVD) only overlap when several workgroups share a CU.  Measured on
 // 2048 pairs of 1024 x 1024: 2D trimmed, 20 iterations 7.99 -> 6.13 ms; 3D vanilla, 10 iterations 8.52 -> 4.43 ms.
-constexpr int pair_min_waves(int d, int qpt, int tmax) {
-    return tmax > 256 ? 1 : (d == 2 ? (qpt <= 2 ? 4 : (qpt <= 4 ? 3 : 1)) : (qpt <= 4 ? ICPX_3D_SMALL_WAVES : 1));
+#ifndef ICPX_2D_Q4_WAVES
+#define ICPX_2D_Q4_WAVES 2
+#endif
+// (the pruned 2D kernel of 4 points per thread spills ~180 registers under a 168-register budget and is bound by
+// the latency of its iteration chain, not by throughput: two workgroups per compute unit without spills)
+constexpr int pair_min_waves(int d, int qpt, int tmax, bool prune = false) {
+    return tmax > 256 ? 1 : (d == 2 ? (qpt <= 2 ? 4 : (qpt <= 4 ? (prune ? ICPX_2D_Q4_WAVES : 3) : 1)) : (qpt <= 4 ? ICPX_3D_SMALL_WAVES : 1));
 }
 
 template <int D, int METHOD, int QPT>
@@ -1079,7 +1084,7 @@ ICPX_DEV int pair_visit(const PairBatch& pb, const int p, const int do_setup, co
 }
 
 template <int D, int METHOD, int QPT, int TMAX, bool PRUNE>
-__global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX)) pair_kernel(const PairBatch pb) {
+__global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX, PRUNE)) pair_kernel(const PairBatch pb) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     // Two ways of handing out pairs, ONE call site of the pair's code (it is large):
     //   plain      workgroup b runs pair b from begin to end;

@@ -100,8 +100,12 @@ def test_nn_empty_and_nonfinite(icp, ob):
 
 def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen):
     """Against the REAL reference kd-tree (oracle/_ref when present, else its restatement):
-    indices may differ only where sqrt(d2) is bit-identical; the count is reported."""
+    indices may differ only where sqrt(d2) is bit-identical (the kd-tree compares sqrt(d2), kdtree.h:140,151, this
+    library d2 then the index: INTEGRATION.md section 4).  The number of such picks is pinned per data set: ONE query
+    of scan1 (source 109, targets 152 / 158), none elsewhere — the whole of the 7.5e-6 deviation of scan1 / vanilla
+    from the reference-order transform that test_scans_converge_bit_exact_and_golden allows for."""
     total = 0
+    expect = {"scan1": 1, "scan2": 0, "scan3": 0}  # (queen: duplicated vertices, exact ties — reported only)
     for name, (q, t) in [("scan1", scans[1]), ("scan2", scans[2]), ("scan3", scans[3]), ("queen", queen)]:
         ki, kd = ob.ref_nn_kdtree(q, t) if ob.ref_lib() is not None else ob.nn_kdtree(q, t)
         idx, d2 = icp.nearest_neighbors(q, t, icp.NN_AUTO)
@@ -109,6 +113,9 @@ def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen):
         diff = np.nonzero(idx != ki)[0]
         for i in diff:
             assert np.sqrt(((t[ki[i]] - q[i]) ** 2).sum()) == np.sqrt(d2[i])
+        assert name not in expect or len(diff) == expect[name], (name, diff)
+        if name == "scan1":
+            assert list(diff) == [109] and {int(idx[109]), int(ki[109])} == {152, 158}
         total += len(diff)
     print("kd-tree tie picks that differ from the (d2, index) rule:", total)
 

@@ -13,20 +13,25 @@ shutil.copy(os.path.join(go, f"{tag}_bench.json"), os.path.join(pr, f"{tag}_benc
 stats = glob.glob(os.path.join(go, f"{tag}_trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(pr, f"{tag}_bench_kernel_stats.csv"))
+stats = glob.glob(os.path.join(go, f"{tag}_c4_trace", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(pr, f"{tag}_c4_grid_kernel_stats.csv"))
 per = defaultdict(lambda: defaultdict(list))
-for d in ("pmc_fetch", "pmc_write", "pmc_valu"):
+for d in ("pmc_fetch", "pmc_write", "pmc_valu", "pmc_lds", "c4_pmc_fetch", "c4_pmc_write"):
     for f in glob.glob(os.path.join(go, f"{tag}_{d}", "*", "*_counter_collection.csv")):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if "icpx::" in row["Kernel_Name"]:
                     per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"_doc": "rocprofv3 --pmc passes (one counter group per run) over `bench.py --steps 3 --warmup 1 "
-               "--no-cpu-baseline --no-extras`; per-launch averages. FETCH_SIZE / WRITE_SIZE are in KB; "
+               "--no-cpu-baseline --no-extras --verify-pairs 0 --no-executed-work` (pair kernels: the launches of the timed steps "
+               "and the ten launched alone after them, same work each) and over `tools/c4_grid_probe.py 3` (grid kernels); per-launch averages. FETCH_SIZE / WRITE_SIZE are in KB; "
                "on gfx950 FETCH_SIZE counts half the bytes of wide coalesced streaming reads "
                "(MI355X_MICROARCH.md), so the raw and the fetch-doubled figure are both given.",
        "kernels": {}}
 for k, cs in per.items():
     e = {c + "_per_launch": sum(v) / len(v) for c, v in cs.items()}
+    e.update({c + "_median": sorted(v)[len(v) // 2] for c, v in cs.items()})
     e["launches_seen"] = max(len(v) for v in cs.values())
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         fz, wz = e["FETCH_SIZE_per_launch"] * 1024, e["WRITE_SIZE_per_launch"] * 1024
