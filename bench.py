@@ -352,6 +352,19 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
                                   "note": "examined records mostly come from L2 (neighbouring queries share cells): the "
                                           "algorithmic figure counts them all; measured HBM bytes are in profiles/ "
                                           "(rNN_counters.json, grid_nn_kernel)"}}
+    # config 4, clustered variant (points on 64 planes: most cells empty) — one correspondence step, build + query
+    srcc, tgtc, _, _ = synth.config4(1_000_000, clustered=True)
+    d_qc, d_tc = torch.from_numpy(srcc).to(dev), torch.from_numpy(tgtc).to(dev)
+    icp_amd.nearest_neighbors(d_qc, d_tc, icp_amd.NN_GRID, device=local_rank, stream=stream, out_idx=idx, out_d2=d2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        icp_amd.nearest_neighbors(d_qc, d_tc, icp_amd.NN_GRID, device=local_rank, stream=stream, out_idx=idx, out_d2=d2)
+    torch.cuda.synchronize()
+    dtc = (time.perf_counter() - t0) / 5
+    ex["c4_clustered_grid_nn_1m_build_plus_query_ms"] = dtc * 1e3
+    ex["c4_clustered_grid_nn_1m_queries_per_s"] = len(srcc) / dtc
+    del d_qc, d_tc
     # config 4, M2: full converge of the 1 M x 1 M pair (vanilla ICP3, max 50 iterations, tol 1e-4)
     drv4 = icp_amd.ICPDriver(icp_amd.ICP3.from_method("vanilla", device=local_rank))
     drv4.set_max_iterations(MAX_ITER)

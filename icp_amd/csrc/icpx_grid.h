@@ -117,7 +117,7 @@ ICPX_DEV int cell_of(const GridParams& gp, const double* p) {
 
 template <int D>
 __global__ void grid_count_kernel(const double* __restrict__ t, GridParams gp, int* __restrict__ cell_id,
-                                  int* __restrict__ counts, int* __restrict__ occupied) {
+                                  int* __restrict__ counts) {
     int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= gp.m) return;
     double p[D];
@@ -125,7 +125,25 @@ __global__ void grid_count_kernel(const double* __restrict__ t, GridParams gp, i
     for (int d = 0; d < D; d++) p[d] = t[j * D + d];
     int c = cell_of<D>(gp, p);
     cell_id[j] = c;
-    if (atomicAdd(&counts[c], 1) == 0) atomicAdd(occupied, 1);
+    // result unused: the atomic does not wait for its return value (a million returning atomics on random
+    // cells were 0.19 ms of the 0.33 ms build)
+    __hip_atomic_fetch_add(&counts[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// number of cells that hold at least one target
+__global__ void __launch_bounds__(256) grid_occupied_kernel(const int* __restrict__ counts, int ncell, int* __restrict__ occupied) {
+    int nz = 0;
+    for (int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; c < ncell;
+         c += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        nz += counts[c] != 0 ? 1 : 0;
+    __shared__ int part[4];
+    nz = wave_sum_int(nz);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = nz;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        nz = part[0] + part[1] + part[2] + part[3];
+        if (nz) atomicAdd(occupied, nz);
+    }
 }
 
 // exclusive scan of counts[0..ncell) into start[0..ncell] (start[ncell] = total) in three steps:
@@ -222,14 +240,84 @@ __global__ void grid_scatter_kernel(const double* __restrict__ t, int64_t m, con
     recs[pos] = r;
 }
 
+// Continuation of a query that has a finite candidate (best, bidx) and has not met the shells' stopping test:
+// instead of more shells (whose cell count grows with the cube of the distance — queries outside the target's
+// box, sparse regions), only the rows of cells that the BALL of the current best can reach are visited, and in
+// each row only the cells within the remaining radius.  Lower bounds per axis come from the inner faces of the
+// slabs exactly as in the shells' stopping test (same slack), so a row or cell is skipped only when everything in
+// it is strictly farther than the current best; cell ranges use cell_coord, the (monotone) function that placed
+// the targets.  best only shrinks, so everything at most as far as the final best is evaluated.
+template <int D>
+ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+                             const double* q, const int (&c)[3], double& best, int& bidx, int& visited) {
+    const double down = 0.99999999999909051;  // 1 - 2^-40
+    double slack[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < D; d++) slack[d] = (dabs(gp.lo[d]) + dabs(gp.hi[d]) + dabs(q[d])) * 2.8421709430404007e-14;  // 2^-45
+    // lower bound of |t - q| along axis d for a target in slab k (0 for the query's own slab)
+    auto gap_of = [&](int d, int k) -> double {
+        double g = 0.0;
+        if (k > c[d]) g = (gp.lo[d] + static_cast<double>(k) * gp.h[d]) - q[d] - slack[d];
+        else if (k < c[d]) g = q[d] - (gp.lo[d] + static_cast<double>(k + 1) * gp.h[d]) - slack[d];
+        return g > 0.0 ? g : 0.0;
+    };
+    // cells of axis d within `rad` of the query (rad: a distance that bounds |t - q| on this axis)
+    auto range_of = [&](int d, double rad, int& k0, int& k1) {
+        const double r = rad * (1.0 + 1.7763568394002505e-15) + 1e-150;  // (1 + 2^-49)
+        const double w = (dabs(q[d]) + r) * 4.4408920985006262e-16;      // 2^-51
+        k0 = cell_coord<D>(gp, q[d] - r - w, d);
+        k1 = cell_coord<D>(gp, q[d] + r + w, d);
+    };
+    int z0 = 0, z1 = 0;
+    if (D == 3) range_of(2, __builtin_sqrt(best), z0, z1);
+    for (int z = z0; z <= z1; z++) {
+        const double gz = D == 3 ? gap_of(2, z) : 0.0;
+        if (gz * gz * down > best) continue;
+        int y0, y1;
+        range_of(1, __builtin_sqrt(best), y0, y1);
+        for (int y = y0; y <= y1; y++) {
+            const double gy = gap_of(1, y);
+            const double far2 = (gz * gz + gy * gy) * down;
+            if (far2 > best) continue;
+            int x0, x1;
+            range_of(0, __builtin_sqrt(best - far2 + best * 9.0949470177292824e-13), x0, x1);  // + 2^-40 best: the subtraction's rounding
+            const int row = (z * gp.g[1] + y) * gp.g[0];
+            const int kb = start[row + x0], ke = start[row + x1 + 1];
+            for (int k0 = kb; k0 < ke; k0 += 4) {
+                GridRec rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) rec[u] = recs[k0 + u < ke ? k0 + u : ke - 1];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    double df = rec[u].x - q[0];
+                    double dist = df * df;
+                    df = rec[u].y - q[1];
+                    dist = dist + df * df;
+                    if (D == 3) {
+                        df = rec[u].z - q[2];
+                        dist = dist + df * df;
+                    }
+                    const int j = static_cast<int>(rec[u].idx);
+                    const bool take = (k0 + u < ke) && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
+                    best = take ? dist : best;
+                    bidx = take ? j : bidx;
+                }
+            }
+            visited += ke - kb;
+        }
+    }
+}
+
 // one query against the grid.  Returns (best d2, lowest index among equal d2); (inf, 0) when no
 // target has a finite distance.
+// (r0, best0, bidx0): the shells below r0 have been visited already, with this result (grid_block_query)
 template <int D>
 ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                          const int* __restrict__ start, const double* q, double& best_out,
-                         int& idx_out, int& visited) {
-    double best = __builtin_inf();
-    int bidx = 0x7fffffff;
+                         int& idx_out, int& visited, const int r0 = 0, const double best0 = __builtin_inf(),
+                         const int bidx0 = 0x7fffffff) {
+    double best = best0;
+    int bidx = bidx0;
     bool qfin = true;
 #pragma unroll
     for (int d = 0; d < D; d++) qfin = qfin && finite_d(q[d]);
@@ -243,7 +331,12 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
         for (int d = 0; d < D; d++)
             slack[d] = (dabs(gp.lo[d]) + dabs(gp.hi[d]) + dabs(q[d])) * 2.8421709430404007e-14;  // 2^-45
         const int gx = gp.g[0], gy = gp.g[1], gz = D == 3 ? gp.g[2] : 1;
-        for (int r = 0; r <= gp.rmax; r++) {
+        for (int r = r0; r <= gp.rmax; r++) {
+            if (r >= 2 && best < __builtin_inf()) {
+                // shells 0 and 1 did not settle it: the rest through the ball of the candidate
+                grid_ball_scan<D>(gp, recs, start, q, c, best, bidx, visited);
+                break;
+            }
             const int zlo = D == 3 ? (c[2] - r > 0 ? c[2] - r : 0) : 0;
             const int zhi = D == 3 ? (c[2] + r < gz - 1 ? c[2] + r : gz - 1) : 0;
             const int ylo = c[1] - r > 0 ? c[1] - r : 0;
@@ -335,6 +428,220 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
     idx_out = bidx == 0x7fffffff ? 0 : bidx;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Block-cooperative query.  The queries are sorted by TILE (grid_query_keys_kernel: tiles of 4 x 4 (x 2) cells,
+// x fastest); a workgroup owns a block of four tiles along x — 16 x 4 (x 2) cells, ~256 queries at two targets
+// per cell — and its queries are one contiguous range of the sorted order (qstart, grid_block_starts_kernel).
+// The cells any of them needs for shells 0 and 1 are the block widened by one cell: those records are staged ONCE
+// in LDS with coalesced loads (SoA, plus the box's slice of the cell start table rebased to LDS positions: 3.4
+// records fetched per query instead of 52), and every lane scans its own 3^D cells from there.  Then the lane stops
+// by the same test as grid_query (best < lower bound of everything outside its visited block) or goes on with
+// shell 2 in global memory.  Same (d2, index) minimum: the rule does not depend on the order of evaluation.
+// Queries that have left their block since the sort (the running cloud of a converge moves) and blocks whose
+// records do not fit take grid_query from shell 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGridBlkRecs = 1152;     // records staged per workgroup (a full block holds 18 x 6 x 4 cells)
+constexpr int kGridBlkRows = 24;
+constexpr int kGridBlkSlice = kGridBlkRows * 19;
+constexpr size_t kGridBlkBytes = sizeof(double) * 3 * kGridBlkRecs + sizeof(int) * (kGridBlkRecs + kGridBlkSlice + 3 * kGridBlkRows + 8);
+
+// tiles per axis; x padded to whole blocks of four tiles
+inline __host__ __device__ void grid_tiles(const GridParams& gp, int dim, int (&nt)[3]) {
+    nt[0] = (((gp.g[0] + 3) >> 2) + 3) & ~3;
+    nt[1] = (gp.g[1] + 3) >> 2;
+    nt[2] = dim == 3 ? (gp.g[2] + 1) >> 1 : 1;
+}
+
+// qstart[b] = first sorted query of block b (b = 0 .. nblocks; qstart[nblocks] = n), from the sorted keys
+__global__ void grid_block_starts_kernel(const uint32_t* __restrict__ keys_sorted, int64_t n, int nblocks, int* __restrict__ qstart) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cur = static_cast<int>(keys_sorted[i] >> 7);  // key = tile << 5 | cell in tile; block = tile >> 2
+    const int prev = i > 0 ? static_cast<int>(keys_sorted[i - 1] >> 7) : -1;
+    for (int b = prev + 1; b <= cur; b++) qstart[b] = static_cast<int>(i);
+    if (i == n - 1)
+        for (int b = cur + 1; b <= nblocks; b++) qstart[b] = static_cast<int>(n);
+}
+
+// Workgroup-wide: stages the block's box.  Returns false (uniformly) when it does not fit.  b0 / b1: the box.
+template <int D>
+ICPX_DEV bool grid_block_stage(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start, const int blk,
+                               char* lds, int (&b0)[3], int (&b1)[3]) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    int nt[3];
+    grid_tiles(gp, D, nt);
+    const int nbx = nt[0] >> 2;
+    const int bx = blk % nbx, ty = (blk / nbx) % nt[1], tz = blk / (nbx * nt[1]);
+    b0[0] = max(16 * bx - 1, 0);
+    b1[0] = min(16 * bx + 16, gp.g[0] - 1);
+    b0[1] = max(4 * ty - 1, 0);
+    b1[1] = min(4 * ty + 4, gp.g[1] - 1);
+    b0[2] = D == 3 ? max(2 * tz - 1, 0) : 0;
+    b1[2] = D == 3 ? min(2 * tz + 2, gp.g[2] - 1) : 0;
+    const int nx = b1[0] - b0[0] + 1, ny = b1[1] - b0[1] + 1, nz = b1[2] - b0[2] + 1;
+    const int nrows = ny * nz;
+    double* sx = reinterpret_cast<double*>(lds);
+    int* sidx = reinterpret_cast<int*>(sx + 3 * kGridBlkRecs);
+    int* slice = sidx + kGridBlkRecs;
+    int* rowoff = slice + kGridBlkSlice;
+    int* rowbeg = rowoff + kGridBlkRows;
+    int* rowcell = rowbeg + kGridBlkRows;
+    int* misc = rowcell + kGridBlkRows;   // [0] total records
+    if (nx < 1 || nrows < 1 || nrows > kGridBlkRows || nx + 1 > 19) return false;  // (uniform)
+    if (tid < 64) {  // wave 0: the rows of the box and their prefix sum
+        int len = 0, beg = 0, cell0 = 0;
+        if (tid < nrows) {
+            const int z = b0[2] + tid / ny, y = b0[1] + tid % ny;
+            cell0 = (z * gp.g[1] + y) * gp.g[0] + b0[0];
+            beg = start[cell0];
+            len = start[cell0 + nx] - beg;
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            incl += tid >= o ? up : 0;
+        }
+        if (tid < nrows) {
+            rowoff[tid] = incl - len;
+            rowbeg[tid] = beg;
+            rowcell[tid] = cell0;
+        }
+        if (tid == 63) misc[0] = incl;
+    }
+    __syncthreads();
+    const int total = misc[0];
+    if (total > kGridBlkRecs) return false;
+    for (int i = tid; i < nrows * (nx + 1); i += T) {
+        const int r = i / (nx + 1), k = i - r * (nx + 1);
+        slice[i] = start[rowcell[r] + k] - rowbeg[r] + rowoff[r];
+    }
+    for (int i = tid; i < total; i += T) {
+        int r = 0;  // the last row whose offset is <= i
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1) {
+            const int t = r + step;
+            r = (t < nrows && rowoff[t] <= i) ? t : r;
+        }
+        const GridRec rec = recs[rowbeg[r] + (i - rowoff[r])];
+        sx[i] = rec.x;
+        sx[kGridBlkRecs + i] = rec.y;
+        if (D == 3) sx[2 * kGridBlkRecs + i] = rec.z;
+        sidx[i] = static_cast<int>(rec.idx);
+    }
+    __syncthreads();
+    return true;
+}
+
+// One query of a staged block (staged: grid_block_stage returned true).  Per lane; no barriers.
+template <int D>
+ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+                               const double* q, const bool staged, const int (&b0)[3], const int (&b1)[3], const char* lds,
+                               double& best_out, int& idx_out, int& visited) {
+    bool qfin = gp.m > 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) qfin = qfin && finite_d(q[d]);
+    if (!qfin) {
+        best_out = __builtin_inf();
+        idx_out = 0;
+        return;
+    }
+    int c[3] = {0, 0, 0};
+    bool inside = staged;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        c[d] = cell_coord<D>(gp, q[d], d);
+        inside = inside && max(c[d] - 1, 0) >= b0[d] && min(c[d] + 1, gp.g[d] - 1) <= b1[d];
+    }
+    if (!inside) {
+        grid_query<D>(gp, recs, start, q, best_out, idx_out, visited);
+        return;
+    }
+    const double* sx = reinterpret_cast<const double*>(lds);
+    const int* sidx = reinterpret_cast<const int*>(sx + 3 * kGridBlkRecs);
+    const int* slice = sidx + kGridBlkRecs;
+    const int nx = b1[0] - b0[0] + 1, ny = b1[1] - b0[1] + 1;
+    double best = __builtin_inf();
+    int bidx = 0x7fffffff;
+    const int xs = max(c[0] - 1, 0) - b0[0], xe = min(c[0] + 1, gp.g[0] - 1) - b0[0] + 1;
+    for (int z = (D == 3 ? max(c[2] - 1, 0) : 0); z <= (D == 3 ? min(c[2] + 1, gp.g[2] - 1) : 0); z++)
+        for (int y = max(c[1] - 1, 0); y <= min(c[1] + 1, gp.g[1] - 1); y++) {
+            const int rr = (z - b0[2]) * ny + (y - b0[1]);
+            const int s = slice[rr * (nx + 1) + xs], e = slice[rr * (nx + 1) + xe];
+            for (int k = s; k < e; k++) {
+                double df = sx[k] - q[0];
+                double dist = df * df;
+                df = sx[kGridBlkRecs + k] - q[1];
+                dist = dist + df * df;
+                if (D == 3) {
+                    df = sx[2 * kGridBlkRecs + k] - q[2];
+                    dist = dist + df * df;
+                }
+                const int j = sidx[k];
+                const bool take = dist < best || (dist == best && j < bidx && bidx != 0x7fffffff);
+                best = take ? dist : best;
+                bidx = take ? j : bidx;
+            }
+            visited += e - s;
+        }
+    // the stopping test of grid_query after shell 1
+    double lb = __builtin_inf();
+    bool all_covered = true;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const double slack = (dabs(gp.lo[d]) + dabs(gp.hi[d]) + dabs(q[d])) * 2.8421709430404007e-14;  // 2^-45
+        const int kl = c[d] - 1, kh = c[d] + 2;
+        if (kl > 0) {
+            all_covered = false;
+            double gap = (q[d] - (gp.lo[d] + static_cast<double>(kl) * gp.h[d])) - slack;
+            gap = gap > 0.0 ? gap : 0.0;
+            lb = gap < lb ? gap : lb;
+        }
+        if (kh < gp.g[d]) {
+            all_covered = false;
+            double gap = ((gp.lo[d] + static_cast<double>(kh) * gp.h[d]) - q[d]) - slack;
+            gap = gap > 0.0 ? gap : 0.0;
+            lb = gap < lb ? gap : lb;
+        }
+    }
+    if (all_covered || best < lb * lb * 0.99999999999909051) {  // (1 - 2^-40)
+        best_out = best;
+        idx_out = bidx == 0x7fffffff ? 0 : bidx;
+    } else {
+        grid_query<D>(gp, recs, start, q, best_out, idx_out, visited, 2, best, bidx);
+    }
+}
+
+// stand-alone query, one workgroup per block of tiles
+template <int D>
+__global__ void __launch_bounds__(256)
+grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec* __restrict__ recs,
+                     const int* __restrict__ start, int64_t* __restrict__ idx, double* __restrict__ d2,
+                     unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm,
+                     const int* __restrict__ qstart) {
+    extern __shared__ __attribute__((aligned(16))) char grid_lds[];
+    const int qs = qstart[blockIdx.x], qe = qstart[blockIdx.x + 1];
+    if (qs >= qe) return;  // (uniform)
+    int b0[3], b1[3];
+    const bool staged = grid_block_stage<D>(gp, recs, start, blockIdx.x, grid_lds, b0, b1);
+    int visited = 0;
+    for (int k = qs + threadIdx.x; k < qe; k += blockDim.x) {
+        const int64_t i = perm[k];
+        double qq[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) qq[d] = q[i * D + d];
+        double best;
+        int bi;
+        grid_block_query<D>(gp, recs, start, qq, staged, b0, b1, grid_lds, best, bi, visited);
+        if (idx) idx[i] = bi;
+        if (d2) d2[i] = best;
+    }
+    if (visited_total) {
+        int v = wave_sum_int(visited);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(visited_total, static_cast<unsigned long long>(v));
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256)
 grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const GridRec* __restrict__ recs,
@@ -343,8 +650,7 @@ grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const Gri
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     int visited = 0;
     const bool live = i < n;
-    // queries are visited in cell order (perm, grid_sort_queries) so that neighbouring lanes walk the
-    // same cells: 1.6x on 1 M random queries
+    // queries are visited in tile order (perm, grid_sort_queries) so that neighbouring lanes walk the same cells
     if (live && perm) i = perm[i];
     if (live) {
         double qq[D];
@@ -362,7 +668,10 @@ grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const Gri
     }
 }
 
-// cell of every query (clamped into the grid) as the sort key of grid_sort_queries
+// Sort key of grid_sort_queries: the query's cell (clamped into the grid) in TILE order — tiles of 4 x 4 (x 2)
+// cells, x fastest over the tiles (the tile count along x padded to a multiple of four: grid_tiles) and inside a
+// tile — so that consecutive queries cover a compact block of cells instead of a run along x, and four tiles
+// along x form the block of one workgroup of the block-cooperative query
 template <int D>
 __global__ void grid_query_keys_kernel(const double* __restrict__ q, int64_t n, GridParams gp,
                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ iota) {
@@ -371,7 +680,11 @@ __global__ void grid_query_keys_kernel(const double* __restrict__ q, int64_t n, 
     double p[D];
 #pragma unroll
     for (int d = 0; d < D; d++) p[d] = q[i * D + d];
-    keys[i] = static_cast<uint32_t>(cell_of<D>(gp, p));
+    const int cx = cell_coord<D>(gp, p[0], 0), cy = cell_coord<D>(gp, p[1], 1), cz = D == 3 ? cell_coord<D>(gp, p[2], 2) : 0;
+    int nt[3];
+    grid_tiles(gp, D, nt);
+    const uint32_t tile = static_cast<uint32_t>(((cz >> 1) * nt[1] + (cy >> 2)) * nt[0] + (cx >> 2));
+    keys[i] = (tile << 5) | static_cast<uint32_t>((((cz & 1) * 4) + (cy & 3)) * 4 + (cx & 3));
     iota[i] = static_cast<uint32_t>(i);
 }
 

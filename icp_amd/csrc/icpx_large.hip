@@ -46,7 +46,9 @@ struct GridIndex {
     int ncell = 0;
     DevBuf recs, start, cell_id, counts, keys, totals;
     // query order by cell (grid_sort_queries); q_perm_n == 0: none
-    DevBuf q_keys, q_keys_out, q_iota, q_perm, q_tmp;
+    DevBuf q_keys, q_keys_out, q_iota, q_perm, q_tmp, q_start;
+    int64_t q_blocks = 0;  // workgroups of the block-cooperative query (q_start: their ranges of q_perm)
+    double occupied_frac = 0.0;  // share of the cells that hold a target (grid_build)
     int64_t q_perm_n = 0;
 };
 
@@ -130,53 +132,78 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost
 // untransformed source (vanilla.cpp:68-88).  MODE 2: Trimmed::compute_matches on transform*a with
 // the squared distance as cost (trimmed.cpp:95-109).  MODE 3: Vanilla's compute_matches on
 // transform*a (opt-in ICPX_FLAG_MATCH_TRANSFORMED, not reference behaviour).
+// qstart != null: block-cooperative (icpx_grid.h) — one workgroup per block of tiles, its queries the range
+// [qstart[b], qstart[b + 1]) of the order `perm`; otherwise one query per thread.
 template <int D, int METHOD, int MODE>
 __global__ void __launch_bounds__(256)
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
-             double max_distance, const uint32_t* __restrict__ perm) {
+             double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart) {
+    extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     if (respect_done && dev->st.done) return;
+    // the query of point i as the method defines it
+    auto query_of = [&](const int64_t i, double (&q)[D]) {
+        if (MODE == 1) {
+#pragma unroll
+            for (int d = 0; d < D; d++) q[d] = src[i * D + d];
+        } else if (MODE == 2 || MODE == 3) {
+            Xf<D> X;
+#pragma unroll
+            for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+            XfRows<D> xr = xf_rows<D>(X);
+            double p[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) p[d] = src[i * D + d];
+            xf_apply<D>(xr, p, q);  // a_current = transform * a, trimmed.cpp:40
+        } else {
+            // c = T * c with the step the previous iteration produced (identity after begin)
+            Xf<D> S;
+#pragma unroll
+            for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
+            XfRows<D> sr = xf_rows<D>(S);
+            double c[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
+            xf_apply<D>(sr, c, q);
+#pragma unroll
+            for (int d = 0; d < D; d++) cur[i * D + d] = q[d];
+        }
+    };
+    auto publish = [&](const int64_t i, const double best, const int bi) {
+        nb_idx[i] = bi;
+        if (MODE == 2) {
+            nb_cost[i] = best;  // trimmed.cpp:101 squaredNorm; selection comes from lg_select_kernel
+        } else {
+            double c = __builtin_sqrt(__builtin_sqrt(best));  // sqrt of kdtree.h:126's Euclidean distance
+            nb_cost[i] = c;
+            sel[i] = (D == 3 && METHOD == ICPX_TRIMMED) ? (c <= max_distance ? 1 : 0) : 1;
+        }
+    };
+    int visited = 0;
+    if (qstart) {
+        const int qs = qstart[blockIdx.x], qe = qstart[blockIdx.x + 1];
+        if (qs >= qe) return;  // (uniform)
+        int b0[3], b1[3];
+        const bool staged = grid_block_stage<D>(gp, recs, start, blockIdx.x, grid_lds, b0, b1);
+        for (int k = qs + threadIdx.x; k < qe; k += blockDim.x) {
+            const int64_t i = perm[k];
+            double q[D], best;
+            int bi;
+            query_of(i, q);
+            grid_block_query<D>(gp, recs, start, q, staged, b0, b1, grid_lds, best, bi, visited);
+            publish(i, best, bi);
+        }
+        return;
+    }
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (perm) i = perm[i];  // cell order of the initial cloud: neighbouring lanes walk the same cells
-    double q[D];
-    if (MODE == 1) {
-#pragma unroll
-        for (int d = 0; d < D; d++) q[d] = src[i * D + d];
-    } else if (MODE == 2 || MODE == 3) {
-        Xf<D> X;
-#pragma unroll
-        for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
-        XfRows<D> xr = xf_rows<D>(X);
-        double p[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) p[d] = src[i * D + d];
-        xf_apply<D>(xr, p, q);  // a_current = transform * a, trimmed.cpp:40
-    } else {
-        // c = T * c with the step the previous iteration produced (identity after begin)
-        Xf<D> S;
-#pragma unroll
-        for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
-        XfRows<D> sr = xf_rows<D>(S);
-        double c[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
-        xf_apply<D>(sr, c, q);
-#pragma unroll
-        for (int d = 0; d < D; d++) cur[i * D + d] = q[d];
-    }
-    double best;
-    int bi, visited = 0;
+    if (perm) i = perm[i];  // tile order of the initial cloud: neighbouring lanes walk the same cells
+    double q[D], best;
+    int bi;
+    query_of(i, q);
     grid_query<D>(gp, recs, start, q, best, bi, visited);
-    nb_idx[i] = bi;
-    if (MODE == 2) {
-        nb_cost[i] = best;  // trimmed.cpp:101 squaredNorm; selection comes from lg_select_kernel
-    } else {
-        double c = __builtin_sqrt(__builtin_sqrt(best));  // sqrt of kdtree.h:126's Euclidean distance
-        nb_cost[i] = c;
-        sel[i] = (D == 3 && METHOD == ICPX_TRIMMED) ? (c <= max_distance ? 1 : 0) : 1;
-    }
+    publish(i, best, bi);
 }
 
 // ---- tiled brute-force correspondence for mid-size clouds --------------------------------------
@@ -933,14 +960,19 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
         ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 2), stream));
         int* d_occ = g->counts.as<int>() + total + 1;
         if (dim == 2)
-            hipLaunchKernelGGL(grid_count_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>(), d_occ);
+            hipLaunchKernelGGL(grid_count_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
         else
-            hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>(), d_occ);
+            hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
         ICPX_HIP(hipGetLastError());
+        g->occupied_frac = 0.0;
         if (nz == 0) break;
+        hipLaunchKernelGGL(grid_occupied_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 1024))), dim3(256), 0,
+                           stream, g->counts.as<int>(), static_cast<int>(total), d_occ);
+        ICPX_HIP(hipGetLastError());
         int occ = 0;
         ICPX_HIP(hipMemcpyAsync(&occ, d_occ, sizeof(int), hipMemcpyDeviceToHost, stream));
         ICPX_HIP(hipStreamSynchronize(stream));
+        g->occupied_frac = static_cast<double>(occ) / static_cast<double>(total);
         if (occ <= 0 || static_cast<double>(m) / occ <= 6.0) break;
         // would the halved grid still fit?
         double next_total = 1.0;
@@ -973,6 +1005,7 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
 // kernels then visit them in that order.  Worth it from a few 10^4 queries on.
 int grid_sort_queries(GridIndex* g, const double* d_q, int64_t n, hipStream_t stream) {
     g->q_perm_n = 0;
+    g->q_blocks = 0;
     if (n < kGridSortMinQueries || g->gp.m <= 0) return ICPX_OK;
     ICPX_TRY(g->q_keys.reserve(sizeof(uint32_t) * n));
     ICPX_TRY(g->q_keys_out.reserve(sizeof(uint32_t) * n));
@@ -986,8 +1019,11 @@ int grid_sort_queries(GridIndex* g, const double* d_q, int64_t n, hipStream_t st
         hipLaunchKernelGGL(grid_query_keys_kernel<3>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp,
                            g->q_keys.as<uint32_t>(), g->q_iota.as<uint32_t>());
     ICPX_HIP(hipGetLastError());
+    int nt[3];
+    grid_tiles(g->gp, g->dim, nt);
+    const int64_t max_key = (static_cast<int64_t>(nt[0]) * nt[1] * nt[2]) << 5;  // tile order, grid_query_keys_kernel
     int bits = 1;
-    while (bits < 32 && (int64_t(1) << bits) < g->ncell) bits++;
+    while (bits < 32 && (int64_t(1) << bits) < max_key) bits++;
     size_t bytes = 0;
     ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, g->q_keys.as<uint32_t>(), g->q_keys_out.as<uint32_t>(),
                                                 g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(), static_cast<int>(n), 0,
@@ -997,14 +1033,33 @@ int grid_sort_queries(GridIndex* g, const double* d_q, int64_t n, hipStream_t st
                                                 g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(), static_cast<int>(n), 0,
                                                 bits, stream));
     g->q_perm_n = n;
+    // ranges of the sorted order that fall into each block of four tiles (block-cooperative query)
+    g->q_blocks = static_cast<int64_t>(nt[0] >> 2) * nt[1] * nt[2];
+    ICPX_TRY(g->q_start.reserve(sizeof(int) * (g->q_blocks + 1)));
+    hipLaunchKernelGGL(grid_block_starts_kernel, dim3(nb), dim3(256), 0, stream, g->q_keys_out.as<uint32_t>(), n,
+                       static_cast<int>(g->q_blocks), g->q_start.as<int>());
+    ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
 
 int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
                       unsigned long long* d_visited, hipStream_t stream) {
     if (n <= 0) return ICPX_OK;
-    unsigned nb = static_cast<unsigned>((n + 255) / 256);
     const uint32_t* perm = g->q_perm_n == n ? g->q_perm.as<uint32_t>() : nullptr;
+    // queries in tile order: one workgroup per block of tiles, its cells staged in LDS (icpx_grid.h)
+    // — for clouds that fill their grid: with most cells empty (surfaces, clusters) the occupied blocks overflow the
+    // staging area and the per-lane walk is faster (clustered config 4: 1.09 vs 1.49 ms)
+    if (perm != nullptr && g->q_blocks > 0 && knobs().grid_coop != 0 && (g->occupied_frac >= 0.5 || knobs().grid_coop == 2)) {
+        if (g->dim == 2)
+            hipLaunchKernelGGL(grid_nn_block_kernel<2>, dim3(static_cast<unsigned>(g->q_blocks)), dim3(256), kGridBlkBytes, stream, d_q,
+                               g->gp, g->recs.as<GridRec>(), g->start.as<int>(), d_idx, d_d2, d_visited, perm, g->q_start.as<int>());
+        else
+            hipLaunchKernelGGL(grid_nn_block_kernel<3>, dim3(static_cast<unsigned>(g->q_blocks)), dim3(256), kGridBlkBytes, stream, d_q,
+                               g->gp, g->recs.as<GridRec>(), g->start.as<int>(), d_idx, d_d2, d_visited, perm, g->q_start.as<int>());
+        ICPX_HIP(hipGetLastError());
+        return ICPX_OK;
+    }
+    const unsigned nb = static_cast<unsigned>((n + 255) / 256);
     if (g->dim == 2)
         hipLaunchKernelGGL(grid_nn_kernel<2>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
                            g->start.as<int>(), d_idx, d_d2, d_visited, perm);
@@ -1199,11 +1254,17 @@ int enqueue_nn(LargeIcp* lg, int respect) {
     const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
     if (lg->feature) return enqueue_feature_match(lg, respect);
     if (!lg->tile) {
-        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect,
-                           lg->src.as<double>(), lg->cur.as<double>(), lg->n, lg->grid->gp,
-                           lg->grid->recs.as<GridRec>(), lg->grid->start.as<int>(), lg->nb_idx.as<int64_t>(),
-                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance,
-                           lg->grid->q_perm_n == lg->n ? lg->grid->q_perm.as<uint32_t>() : nullptr);
+        const GridIndex* g = lg->grid;
+        const uint32_t* perm = g->q_perm_n == lg->n ? g->q_perm.as<uint32_t>() : nullptr;
+        // block-cooperative only on request (ICPX_GRID_COOP=2): the order is that of begin(), and once the running cloud has
+        // moved by more than a cell most queries have left their block's staged cells (config 4 converge: 26.6 vs 19.4 ms)
+        const bool blk = perm != nullptr && g->q_blocks > 0 && knobs().grid_coop == 2;
+        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(blk ? static_cast<unsigned>(g->q_blocks) : nb), dim3(256),
+                           blk ? kGridBlkBytes : 0, lg->stream, dev, respect,
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->n, g->gp,
+                           g->recs.as<GridRec>(), g->start.as<int>(), lg->nb_idx.as<int64_t>(),
+                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, perm,
+                           blk ? g->q_start.as<int>() : nullptr);
         ICPX_HIP(hipGetLastError());
         return ICPX_OK;
     }

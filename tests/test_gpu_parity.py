@@ -840,6 +840,35 @@ def test_config4_grid_nn_one_million_points(icp, ob):
         assert np.all(d2 >= 0) and np.all(np.isfinite(d2))
 
 
+def test_grid_cooperative_query_is_bit_identical(icp, knob):
+    """The block-cooperative grid query (queries in tile order, a block's cells staged in LDS; from 32 768 queries on) against
+    the per-lane walk (ICPX_GRID_COOP=0) on ALL queries, and against the brute-force kernel at a size it covers:
+    uniform, clustered (non-uniform cells: many waves fall back), a lattice (every distance tied many times) and
+    queries far outside the target's box."""
+    from icp_amd import synth
+    rng = np.random.default_rng(11)
+    cases = []
+    src, tgt, _, _ = synth.config4(1_000_000)
+    cases.append(("config4", src, tgt, False))
+    src, tgt, _, _ = synth.config4(300_000, clustered=True)
+    cases.append(("clustered", src, tgt, False))
+    lat = np.stack(np.meshgrid(np.arange(36.0), np.arange(36.0), np.arange(36.0), indexing="ij"), -1).reshape(-1, 3)
+    cases.append(("lattice", lat[rng.permutation(len(lat))][:40_000] + 0.5, lat, True))
+    far = rng.uniform(-30, 30, (40_000, 3))
+    cases.append(("outside", far, rng.uniform(-10, 10, (50_000, 3)), True))
+    q2 = rng.uniform(-10, 10, (60_000, 2))
+    cases.append(("2d", q2, rng.uniform(-10, 10, (45_000, 2)), True))
+    for name, q, t, brute in cases:
+        knob.set("ICPX_GRID_COOP", "2")  # block-cooperative whatever the grid's fill (1, the default: well-filled grids only)
+        i1, d1 = icp.nearest_neighbors(q, t, icp.NN_GRID)
+        knob.set("ICPX_GRID_COOP", "0")
+        i0, d0 = icp.nearest_neighbors(q, t, icp.NN_GRID)
+        assert np.array_equal(i1, i0) and np.array_equal(d1, d0), name
+        if brute:
+            ib, db = icp.nearest_neighbors(q, t, icp.NN_BRUTE)
+            assert np.array_equal(i1, ib) and np.array_equal(d1, db), name
+
+
 def test_config4_converge_recovers_known_transform(icp):
     """Full converge at 1 M points (50 iterations; at this density point-to-point ICP creeps, the
     oracle does the same at smaller n): re-running is bit-reproducible and the estimate has moved
