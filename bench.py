@@ -364,6 +364,16 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
     dtc = (time.perf_counter() - t0) / 5
     ex["c4_clustered_grid_nn_1m_build_plus_query_ms"] = dtc * 1e3
     ex["c4_clustered_grid_nn_1m_queries_per_s"] = len(srcc) / dtc
+    # f3: the linear BVH (icpx_bvh.h) beside the grid on the same clouds (same results; the grid wins on both —
+    # the BVH is for clouds that collapse into a few grid cells: tools/degenerate_probe.py, 1.5 ms against 29 ms)
+    for tag, qq, tt in (("c4", d_q, d_t), ("c4_clustered", d_qc, d_tc)):
+        icp_amd.nearest_neighbors(qq, tt, icp_amd.NN_BVH, device=local_rank, stream=stream, out_idx=idx, out_d2=d2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            icp_amd.nearest_neighbors(qq, tt, icp_amd.NN_BVH, device=local_rank, stream=stream, out_idx=idx, out_d2=d2)
+        torch.cuda.synchronize()
+        ex[tag + "_bvh_nn_1m_build_plus_query_ms"] = (time.perf_counter() - t0) / 3 * 1e3
     del d_qc, d_tc
     # config 4, M2: full converge of the 1 M x 1 M pair (vanilla ICP3, max 50 iterations, tol 1e-4)
     drv4 = icp_amd.ICPDriver(icp_amd.ICP3.from_method("vanilla", device=local_rank))

@@ -7,8 +7,8 @@ benchmarks use (synth.py).
 """
 from .api import (ICP2, ICP3, Config, ConvergenceState, ICPDriver, Match, converge_batch,
                   make_criteria, nearest_neighbors)
-from ._lib import IcpxError, NN_AUTO, NN_BRUTE, NN_GRID, TRIMMED, VANILLA
+from ._lib import IcpxError, NN_AUTO, NN_BRUTE, NN_GRID, NN_BVH, TRIMMED, VANILLA
 
 __all__ = ["ICP2", "ICP3", "Config", "ConvergenceState", "ICPDriver", "Match", "converge_batch",
-           "make_criteria", "nearest_neighbors", "IcpxError", "NN_AUTO", "NN_BRUTE", "NN_GRID",
+           "make_criteria", "nearest_neighbors", "IcpxError", "NN_AUTO", "NN_BRUTE", "NN_GRID", "NN_BVH",
            "TRIMMED", "VANILLA"]

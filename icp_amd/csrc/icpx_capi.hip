@@ -288,6 +288,7 @@ struct Workspace {
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
     DevBuf tperm, grids, cstart, hcert;  // grid-pruned search of the batch entry point
     GridIndex* grid = nullptr;    // grow-only uniform-grid index of the stand-alone queries
+    BvhIndex* bvh = nullptr;      // likewise, ICPX_NN_BVH
     // pinned staging of the offset arrays, so that a stream-ordered call can return before they are consumed
     int64_t* h_off = nullptr;
     size_t h_off_cap = 0;
@@ -430,7 +431,7 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     // against 2.1 ms through the grid), so handles keep it; ICPX_PRUNE_HANDLES=1 sends them through the
     // grid-pruned kernels of the batch path (tests do, to run the whole handle suite over those kernels)
     const bool prune_handles = knobs().prune_handles != 0;
-    bool fused = h->prm.nn_mode != ICPX_NN_GRID && fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles) &&
+    bool fused = h->prm.nn_mode != ICPX_NN_GRID && h->prm.nn_mode != ICPX_NN_BVH && fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles) &&
                  static_cast<double>(n) * static_cast<double>(m) <= single_max &&
                  h->method != ICPX_FEATURE_AWARE &&  // feature_aware and the opt-in corrected modes run on
                  h->prm.flags == 0;                  // the multi-kernel path only
@@ -1060,7 +1061,7 @@ int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out
     icpx_params prm;
     icpx_default_params(&prm);
     if (params) prm = *params;
-    if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_GRID)
+    if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_BVH)
         return fail(ICPX_ERR_INVALID, "unknown nn_mode %d", prm.nn_mode);
     if (prm.flags < 0 || prm.flags > 7) return fail(ICPX_ERR_INVALID, "unknown flags %d", prm.flags);
     int dev = 0;
@@ -1311,7 +1312,7 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
     return guarded([&]() -> int {
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
     if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "negative cloud size");
-    if (mode < ICPX_NN_AUTO || mode > ICPX_NN_GRID) return fail(ICPX_ERR_INVALID, "unknown nn mode %d", mode);
+    if (mode < ICPX_NN_AUTO || mode > ICPX_NN_BVH) return fail(ICPX_ERR_INVALID, "unknown nn mode %d", mode);
     if (n == 0) return ICPX_OK;
     if (!queries || (m > 0 && !targets)) return fail(ICPX_ERR_INVALID, "null queries/targets");
     if (n > INT32_MAX / 4 || m > INT32_MAX / 4) return fail(ICPX_ERR_UNSUPPORTED, "cloud too large");
@@ -1352,9 +1353,16 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
     bool use_grid = mode == ICPX_NN_GRID ||
                     (mode == ICPX_NN_AUTO && static_cast<double>(n) * static_cast<double>(m) > 512.0 * 1024 * 1024);  // measured crossover of one build + query: ~3e4 x 3e4
     if (m == 0) use_grid = false;
-    if (use_grid) {
+    if (m == 0) {
+        hipLaunchKernelGGL(nn_no_targets_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, n, d_idx, d_d2);
+        ICPX_HIP(hipGetLastError());
+    } else if (mode == ICPX_NN_BVH) {
+        if (!ws.bvh) ICPX_TRY(bvh_create(&ws.bvh));
+        ICPX_TRY(bvh_nn_oneshot(ws.bvh, dim, d_q, n, d_t, m, d_idx, d_d2, stream));
+    } else if (use_grid) {
         if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
-        ICPX_TRY(grid_nn_oneshot(ws.grid, dim, d_q, n, d_t, m, d_idx, d_d2, stream));
+        if (mode == ICPX_NN_AUTO && !ws.bvh) ICPX_TRY(bvh_create(&ws.bvh));
+        ICPX_TRY(grid_nn_oneshot(ws.grid, dim, d_q, n, d_t, m, d_idx, d_d2, stream, mode == ICPX_NN_AUTO ? ws.bvh : nullptr));
     } else {
         // (query tiles) x (target splits) so that the launch fills the chip; f32 filter + exact
         // refinement (nn_tile_kernel).  ICPX_FILTER=0 (development) selects the plain f64 kernel.

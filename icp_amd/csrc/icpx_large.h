@@ -37,7 +37,18 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
 int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
                       unsigned long long* d_visited, hipStream_t stream);
 int grid_profile(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, hipStream_t stream, double* out);
+struct BvhIndex;
+// degenerate_to (may be null): the index to use instead when the grid turns out degenerate (grid_degenerate)
 int grid_nn_oneshot(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m,
-                    int64_t* d_idx, double* d_d2, hipStream_t stream);
+                    int64_t* d_idx, double* d_d2, hipStream_t stream, BvhIndex* degenerate_to);
+
+// Linear BVH over one target cloud (icpx_bvh.h): the alternative index for clouds that fill their bounding box unevenly.
+struct BvhIndex;
+int bvh_create(BvhIndex** out);
+void bvh_destroy(BvhIndex* b);
+// d_t: DEVICE pointer, AoS dim x m.  Synchronises the stream once (bounding box read-back).
+int bvh_build(BvhIndex* b, int dim, const double* d_t, int64_t m, hipStream_t stream);
+int bvh_nn_oneshot(BvhIndex* b, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m,
+                   int64_t* d_idx, double* d_d2, hipStream_t stream);
 
 }  // namespace icpx

@@ -25,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "icpx_filter.h"
+#include "icpx_bvh.h"
 #include "icpx_grid.h"
 #include "icpx_large.h"
 #include "icpx_math.h"
@@ -49,7 +50,26 @@ struct GridIndex {
     DevBuf q_keys, q_keys_out, q_iota, q_perm, q_tmp, q_start;
     int64_t q_blocks = 0;  // workgroups of the block-cooperative query (q_start: their ranges of q_perm)
     double occupied_frac = 0.0;  // share of the cells that hold a target (grid_build)
+    double per_occupied = 0.0;   // targets per occupied cell after the refinement (grid_build)
     int64_t q_perm_n = 0;
+};
+
+struct BvhIndex {
+    int dim = 0;
+    int64_t m = 0;
+    int P = 0;             // leaves (power of two)
+    BvhFrame frame{};      // Morton grid over the targets' bounding box (also orders the queries)
+    DevBuf recs, box, keys, keys_out, iota, perm, tmp, bbox;
+    DevBuf q_perm;         // Morton order of the queries (bvh_sort_queries); q_perm_n == 0: none
+    int64_t q_perm_n = 0;
+    BvhView view() const {
+        BvhView v;
+        v.box = box.as<float>();
+        v.recs = recs.as<GridRec>();
+        v.m = m;
+        v.P = P;
+        return v;
+    }
 };
 
 struct LargeDev {
@@ -76,6 +96,8 @@ struct LargeIcp {
     int nblk = 0;         // partials per summed term: 4096-point blocks, or 64-point groups when `groups`
     bool groups = false;  // n <= kGroupSumMaxN
     GridIndex* grid = nullptr;
+    BvhIndex* bvh = nullptr;   // built instead of / after the grid: nn = bvh, or nn = auto with a degenerate grid
+    bool use_bvh = false;
     DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
     // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
     DevBuf sort_keys, sort_iota, sort_order, sort_tmp;
@@ -139,7 +161,7 @@ __global__ void __launch_bounds__(256)
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
-             double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart) {
+             double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     if (respect_done && dev->st.done) return;
     // the query of point i as the method defines it
@@ -181,6 +203,20 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         }
     };
     int visited = 0;
+    if (bvh.P > 0) {
+        // the BVH instead of the grid (icpx_bvh.h): the launch reserved the LDS copy of the tree's top levels
+        float* top = reinterpret_cast<float*>(grid_lds);
+        bvh_stage_top(bvh, top);
+        int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+        if (i >= n) return;
+        if (perm) i = perm[i];  // Hilbert order of the initial cloud
+        double q[D], best;
+        int bi;
+        query_of(i, q);
+        bvh_query<D>(bvh, top, q, best, bi, visited);
+        publish(i, best, bi);
+        return;
+    }
     if (qstart) {
         const int qs = qstart[blockIdx.x], qe = qstart[blockIdx.x + 1];
         if (qs >= qe) return;  // (uniform)
@@ -873,10 +909,15 @@ int grid_create(GridIndex** out) {
 void grid_destroy(GridIndex* g) {
     if (!g) return;
     for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys, &g->totals, &g->q_keys, &g->q_keys_out,
-                      &g->q_iota, &g->q_perm, &g->q_tmp})
+                      &g->q_iota, &g->q_perm, &g->q_tmp, &g->q_start})
         b->release();
     delete g;
 }
+
+// The cell budget could not bring the occupied cells below this many targets on average: the cloud sits in a
+// few spots of a large box (far-apart clusters), every query would scan thousands of records — the BVH's case.
+constexpr double kGridDegenerate = 48.0;
+bool grid_degenerate(const GridIndex* g) { return g->per_occupied > kGridDegenerate; }
 
 int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream) {
     g->dim = dim;
@@ -965,6 +1006,7 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
             hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
         ICPX_HIP(hipGetLastError());
         g->occupied_frac = 0.0;
+        g->per_occupied = static_cast<double>(m);  // (all targets in one point: one cell)
         if (nz == 0) break;
         hipLaunchKernelGGL(grid_occupied_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 1024))), dim3(256), 0,
                            stream, g->counts.as<int>(), static_cast<int>(total), d_occ);
@@ -973,6 +1015,7 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
         ICPX_HIP(hipMemcpyAsync(&occ, d_occ, sizeof(int), hipMemcpyDeviceToHost, stream));
         ICPX_HIP(hipStreamSynchronize(stream));
         g->occupied_frac = static_cast<double>(occ) / static_cast<double>(total);
+        g->per_occupied = occ > 0 ? static_cast<double>(m) / occ : 0.0;
         if (occ <= 0 || static_cast<double>(m) / occ <= 6.0) break;
         // would the halved grid still fit?
         double next_total = 1.0;
@@ -1108,10 +1151,150 @@ int grid_profile(GridIndex* g, int dim, const double* d_q, int64_t n, const doub
 }
 
 int grid_nn_oneshot(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
-                    double* d_d2, hipStream_t stream) {
+                    double* d_d2, hipStream_t stream, BvhIndex* degenerate_to) {
     int rc = grid_build(g, dim, d_t, m, stream);
+    if (rc == ICPX_OK && degenerate_to != nullptr && grid_degenerate(g))
+        return bvh_nn_oneshot(degenerate_to, dim, d_q, n, d_t, m, d_idx, d_d2, stream);  // (declared in icpx_large.h)
     if (rc == ICPX_OK) rc = grid_sort_queries(g, d_q, n, stream);
     if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, d_idx, d_d2, nullptr, stream);
+    if (rc == ICPX_OK) {
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// BVH host side (icpx_bvh.h)
+// ------------------------------------------------------------------------------------------
+
+int bvh_create(BvhIndex** out) {
+    *out = new (std::nothrow) BvhIndex();
+    return *out ? ICPX_OK : fail(ICPX_ERR_NOMEM, "out of host memory");
+}
+
+void bvh_destroy(BvhIndex* b) {
+    if (!b) return;
+    for (DevBuf* d : {&b->recs, &b->box, &b->keys, &b->keys_out, &b->iota, &b->perm, &b->tmp, &b->bbox, &b->q_perm}) d->release();
+    delete b;
+}
+
+namespace {
+// Morton order of `n` points (device, AoS) in the index's frame -> out (u32 permutation)
+int bvh_morton_order(BvhIndex* b, const double* d_p, int64_t n, DevBuf& out, hipStream_t stream) {
+    ICPX_TRY(b->keys.reserve(sizeof(uint64_t) * n));
+    ICPX_TRY(b->keys_out.reserve(sizeof(uint64_t) * n));
+    ICPX_TRY(b->iota.reserve(sizeof(uint32_t) * n));
+    ICPX_TRY(out.reserve(sizeof(uint32_t) * n));
+    const unsigned nb = static_cast<unsigned>((n + 255) / 256);
+    if (b->dim == 2)
+        hipLaunchKernelGGL(bvh_keys_kernel<2>, dim3(nb), dim3(256), 0, stream, d_p, n, b->frame, b->keys.as<uint64_t>(), b->iota.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(bvh_keys_kernel<3>, dim3(nb), dim3(256), 0, stream, d_p, n, b->frame, b->keys.as<uint64_t>(), b->iota.as<uint32_t>());
+    ICPX_HIP(hipGetLastError());
+    size_t bytes = 0;
+    const int bits = b->dim == 3 ? 63 : 62;
+    ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, b->keys.as<uint64_t>(), b->keys_out.as<uint64_t>(), b->iota.as<uint32_t>(),
+                                                out.as<uint32_t>(), static_cast<int>(n), 0, bits, stream));
+    ICPX_TRY(b->tmp.reserve(bytes ? bytes : 1));
+    ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(b->tmp.p, bytes, b->keys.as<uint64_t>(), b->keys_out.as<uint64_t>(), b->iota.as<uint32_t>(),
+                                                out.as<uint32_t>(), static_cast<int>(n), 0, bits, stream));
+    return ICPX_OK;
+}
+}  // namespace
+
+int bvh_build(BvhIndex* b, int dim, const double* d_t, int64_t m, hipStream_t stream) {
+    b->dim = dim;
+    b->m = m;
+    b->P = 0;
+    b->q_perm_n = 0;
+    if (m <= 0) return ICPX_OK;
+    if (m > (int64_t(1) << 30)) return fail(ICPX_ERR_UNSUPPORTED, "bvh: target cloud too large");
+    // 1. bounding box of the finite targets (the grid's kernel) -> frame of the Morton codes
+    ICPX_TRY(b->bbox.reserve(sizeof(unsigned long long) * 6));
+    unsigned long long init[6] = {~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
+    ICPX_HIP(hipMemcpyAsync(b->bbox.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    const int blocks = static_cast<int>(std::min<int64_t>((m + 255) / 256, 512));
+    if (dim == 2)
+        hipLaunchKernelGGL(grid_bbox_kernel<2>, dim3(blocks), dim3(256), 0, stream, d_t, m, b->bbox.as<unsigned long long>());
+    else
+        hipLaunchKernelGGL(grid_bbox_kernel<3>, dim3(blocks), dim3(256), 0, stream, d_t, m, b->bbox.as<unsigned long long>());
+    ICPX_HIP(hipGetLastError());
+    unsigned long long keys[6];
+    ICPX_HIP(hipMemcpyAsync(keys, b->bbox.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
+    ICPX_HIP(hipStreamSynchronize(stream));
+    const bool any = keys[0] != ~0ULL;
+    const double cells = dim == 3 ? 2097152.0 : 2147483648.0;  // 2^21, 2^31: the Hilbert grid (bvh_morton)
+    for (int d = 0; d < 3; d++) {
+        b->frame.lo[d] = 0.0;
+        b->frame.scale[d] = 0.0;
+        if (d < dim && any) {
+            const double lo = f64_unkey(keys[d]), hi = f64_unkey(keys[3 + d]);
+            b->frame.lo[d] = lo;
+            const double sc = hi > lo ? cells / (hi - lo) : 0.0;
+            b->frame.scale[d] = std::isfinite(sc) ? sc : 0.0;
+        }
+    }
+    // 2. Morton order, records in that order
+    ICPX_TRY(bvh_morton_order(b, d_t, m, b->perm, stream));
+    ICPX_TRY(b->recs.reserve(sizeof(GridRec) * m));
+    const unsigned mb = static_cast<unsigned>((m + 255) / 256);
+    if (dim == 2)
+        hipLaunchKernelGGL(bvh_gather_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, m, b->perm.as<uint32_t>(), b->recs.as<GridRec>());
+    else
+        hipLaunchKernelGGL(bvh_gather_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, m, b->perm.as<uint32_t>(), b->recs.as<GridRec>());
+    ICPX_HIP(hipGetLastError());
+    // 3. leaf boxes, then the inner levels bottom-up
+    const int64_t leaves = (m + kBvhLeaf - 1) / kBvhLeaf;
+    int P = 1;
+    while (P < leaves) P <<= 1;
+    ICPX_TRY(b->box.reserve(sizeof(float) * 6 * 2 * static_cast<size_t>(P)));
+    const unsigned lb = static_cast<unsigned>((P + 255) / 256);
+    if (dim == 2)
+        hipLaunchKernelGGL(bvh_leaf_kernel<2>, dim3(lb), dim3(256), 0, stream, b->recs.as<GridRec>(), m, P, b->box.as<float>());
+    else
+        hipLaunchKernelGGL(bvh_leaf_kernel<3>, dim3(lb), dim3(256), 0, stream, b->recs.as<GridRec>(), m, P, b->box.as<float>());
+    ICPX_HIP(hipGetLastError());
+    int lvl = P >> 1;
+    for (; lvl > 256; lvl >>= 1) {
+        hipLaunchKernelGGL(bvh_level_kernel, dim3(static_cast<unsigned>((lvl + 255) / 256)), dim3(256), 0, stream, b->box.as<float>(), lvl);
+        ICPX_HIP(hipGetLastError());
+    }
+    if (lvl >= 1) {
+        hipLaunchKernelGGL(bvh_top_kernel, dim3(1), dim3(256), 0, stream, b->box.as<float>(), lvl);
+        ICPX_HIP(hipGetLastError());
+    }
+    b->P = P;
+    return ICPX_OK;
+}
+
+// Morton order of the queries (in the targets' frame): neighbouring lanes then take the same path through the tree
+int bvh_sort_queries(BvhIndex* b, const double* d_q, int64_t n, hipStream_t stream) {
+    b->q_perm_n = 0;
+    if (n < kGridSortMinQueries || b->P <= 0) return ICPX_OK;
+    ICPX_TRY(bvh_morton_order(b, d_q, n, b->q_perm, stream));
+    b->q_perm_n = n;
+    return ICPX_OK;
+}
+
+int bvh_query_launch(const BvhIndex* b, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
+                     unsigned long long* d_visited, hipStream_t stream) {
+    if (n <= 0) return ICPX_OK;
+    const uint32_t* perm = b->q_perm_n == n ? b->q_perm.as<uint32_t>() : nullptr;
+    const unsigned nb = static_cast<unsigned>((n + 255) / 256);
+    if (b->dim == 2)
+        hipLaunchKernelGGL(bvh_nn_kernel<2>, dim3(nb), dim3(256), 0, stream, d_q, n, b->view(), d_idx, d_d2, d_visited, perm);
+    else
+        hipLaunchKernelGGL(bvh_nn_kernel<3>, dim3(nb), dim3(256), 0, stream, d_q, n, b->view(), d_idx, d_d2, d_visited, perm);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+int bvh_nn_oneshot(BvhIndex* b, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
+                   double* d_d2, hipStream_t stream) {
+    int rc = bvh_build(b, dim, d_t, m, stream);
+    if (rc == ICPX_OK) rc = bvh_sort_queries(b, d_q, n, stream);
+    if (rc == ICPX_OK) rc = bvh_query_launch(b, d_q, n, d_idx, d_d2, nullptr, stream);
     if (rc == ICPX_OK) {
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
@@ -1155,6 +1338,7 @@ void large_destroy(LargeIcp* lg) {
                       &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd})
         b->release();
     grid_destroy(lg->grid);
+    bvh_destroy(lg->bvh);
     if (lg->h_done) (void)hipHostFree(lg->h_done);
     delete lg;
 }
@@ -1254,6 +1438,15 @@ int enqueue_nn(LargeIcp* lg, int respect) {
     const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
     if (lg->feature) return enqueue_feature_match(lg, respect);
     if (!lg->tile) {
+        if (lg->use_bvh) {
+            const BvhIndex* bv = lg->bvh;
+            hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), sizeof(float) * 6 * kBvhTopNodes, lg->stream, dev,
+                               respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, GridParams{}, nullptr, nullptr,
+                               lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance,
+                               bv->q_perm_n == lg->n ? bv->q_perm.as<uint32_t>() : nullptr, nullptr, bv->view());
+            ICPX_HIP(hipGetLastError());
+            return ICPX_OK;
+        }
         const GridIndex* g = lg->grid;
         const uint32_t* perm = g->q_perm_n == lg->n ? g->q_perm.as<uint32_t>() : nullptr;
         // block-cooperative only on request (ICPX_GRID_COOP=2): the order is that of begin(), and once the running cloud has
@@ -1264,7 +1457,7 @@ int enqueue_nn(LargeIcp* lg, int respect) {
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, g->gp,
                            g->recs.as<GridRec>(), g->start.as<int>(), lg->nb_idx.as<int64_t>(),
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, perm,
-                           blk ? g->q_start.as<int>() : nullptr);
+                           blk ? g->q_start.as<int>() : nullptr, BvhView{});
         ICPX_HIP(hipGetLastError());
         return ICPX_OK;
     }
@@ -1422,8 +1615,10 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     }
     // correspondence engine: tiled brute force for mid-size clouds, the uniform grid beyond
     // (ICPX_NN_GRID / ICPX_NN_BRUTE force one or the other)
+    lg->use_bvh = false;
     lg->tile = lg->feature || lg->prm.nn_mode == ICPX_NN_BRUTE ||
-               (lg->prm.nn_mode != ICPX_NN_GRID && static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
+               (lg->prm.nn_mode != ICPX_NN_GRID && lg->prm.nn_mode != ICPX_NN_BVH &&
+                static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
     if (lg->tile) {
         const int64_t ntq = (n + kTileQueries - 1) / kTileQueries;
         int64_t splits = (768 + ntq - 1) / ntq;                       // aim at ~3 workgroups per CU
@@ -1439,9 +1634,21 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         ICPX_TRY(lg->part_d2.reserve(sizeof(double) * static_cast<size_t>(splits) * n));
         ICPX_TRY(lg->part_idx.reserve(sizeof(int32_t) * static_cast<size_t>(splits) * n));
     } else {
-        ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
-        // the running cloud moves little between iterations: its initial cell order stays coherent
-        ICPX_TRY(grid_sort_queries(lg->grid, lg->cur.as<double>(), n, lg->stream));
+        // grid, or the BVH: on request (nn = bvh), or when the grid's cell budget leaves the cloud in a few cells
+        // (far-apart clusters) and nothing was forced
+        lg->use_bvh = lg->prm.nn_mode == ICPX_NN_BVH;
+        if (!lg->use_bvh) {
+            ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
+            lg->use_bvh = lg->prm.nn_mode == ICPX_NN_AUTO && grid_degenerate(lg->grid);
+        }
+        if (lg->use_bvh) {
+            if (!lg->bvh) ICPX_TRY(bvh_create(&lg->bvh));
+            ICPX_TRY(bvh_build(lg->bvh, D, lg->dst.as<double>(), m, lg->stream));
+            ICPX_TRY(bvh_sort_queries(lg->bvh, lg->cur.as<double>(), n, lg->stream));
+        } else {
+            // the running cloud moves little between iterations: its initial cell order stays coherent
+            ICPX_TRY(grid_sort_queries(lg->grid, lg->cur.as<double>(), n, lg->stream));
+        }
     }
     if (lg->feature) {
         // the reference keeps the dense n x m feature-distance matrix too (feature_aware.h:60)

@@ -185,4 +185,12 @@ __global__ void nn_merge_kernel(int64_t n, int splits, const double* __restrict_
     if (d2) d2[i] = best;
 }
 
+// no targets at all: every query gets (index 0, +inf) — what the search loops leave when nothing is below +inf
+__global__ void nn_no_targets_kernel(int64_t n, int64_t* __restrict__ idx, double* __restrict__ d2) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (idx) idx[i] = 0;
+    if (d2) d2[i] = __builtin_inf();
+}
+
 }  // namespace icpx

@@ -60,7 +60,10 @@ enum icpx_method {
 enum icpx_nn_mode {
     ICPX_NN_AUTO = 0,  /* brute force (LDS tiles, f32 filter + exact f64) up to ~3e4 x 3e4, uniform grid beyond */
     ICPX_NN_BRUTE = 1, /* LDS-tiled brute force                                     */
-    ICPX_NN_GRID = 2   /* exact uniform-grid search                                 */
+    ICPX_NN_GRID = 2,  /* exact uniform-grid search                                 */
+    ICPX_NN_BVH = 3    /* exact search through a linear bounding-volume hierarchy (Morton order, implicit
+                          binary tree): the stand-in for the reference's kd-tree (kdtree.h:96-154) on clouds
+                          that fill their bounding box very unevenly.  Same results as the other modes */
 };
 
 /* Opt-in corrections of reference quirks (§8 f4).  NOT reference behaviour:

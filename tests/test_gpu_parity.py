@@ -154,11 +154,11 @@ def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k, 
     assert abs(rs.cost - r.cost) < 1e-12
 
 
-@pytest.mark.parametrize("nn", ["auto", "grid"])
+@pytest.mark.parametrize("nn", ["auto", "grid", "bvh"])
 @pytest.mark.parametrize("method", ["vanilla", "trimmed"])
 def test_queen_large_path(icp, ob, queen, traces, method, nn):
     """BASELINE config 3 (10 720 points) on the multi-kernel path: tiled brute-force NN (auto at this
-    size) and the uniform-grid NN (forced), multi-kernel reductions."""
+    size), the uniform-grid NN and the BVH (forced), multi-kernel reductions."""
     src, dst = queen
     cfg = icp.Config()
     cfg.set("nn", nn)
@@ -867,6 +867,56 @@ def test_grid_cooperative_query_is_bit_identical(icp, knob):
         if brute:
             ib, db = icp.nearest_neighbors(q, t, icp.NN_BRUTE)
             assert np.array_equal(i1, ib) and np.array_equal(d1, db), name
+
+
+def test_bvh_search_is_bit_identical(icp, ob, scans, queen):
+    """ICPX_NN_BVH (linear BVH, icpx_bvh.h) returns the same lexicographic (d2, index) minimum as the brute-force and
+    grid searches: the reference's scans and queen.ply (duplicated vertices: exact ties), a lattice (every distance tied
+    many times), clustered clouds (the case it exists for), queries far outside the targets' box, degenerate extents,
+    non-finite coordinates, tiny and empty clouds."""
+    from icp_amd import synth
+    rng = np.random.default_rng(23)
+    cases = [("scan1", *scans[1]), ("scan2", *scans[2]), ("queen", *queen)]
+    lat = np.stack(np.meshgrid(np.arange(30.0), np.arange(30.0), np.arange(30.0), indexing="ij"), -1).reshape(-1, 3)
+    cases.append(("lattice", lat[rng.permutation(len(lat))][:20_000] + 0.5, lat))
+    src, tgt, _, _ = synth.config4(200_000, clustered=True)
+    cases.append(("clustered", src[:50_000], tgt))
+    cases.append(("outside", rng.uniform(-40, 40, (40_000, 3)), rng.uniform(-10, 10, (60_000, 3))))
+    flat = rng.uniform(-5, 5, (30_000, 3))
+    flat[:, 2] = 1.25                                           # all targets in one plane
+    cases.append(("plane", rng.uniform(-6, 6, (35_000, 3)), flat))
+    cases.append(("2d", rng.uniform(-10, 10, (40_000, 2)), rng.uniform(-10, 10, (33_333, 2))))
+    cases.append(("dups", rng.uniform(0, 1, (2_000, 3)), np.repeat(rng.uniform(0, 1, (300, 3)), 7, axis=0)))
+    cases.append(("tiny", rng.uniform(0, 1, (100, 3)), rng.uniform(0, 1, (5, 3))))
+    bad_t = rng.uniform(-1, 1, (5_000, 3))
+    bad_t[::97, 1] = np.nan
+    bad_t[5::131, 0] = np.inf
+    bad_q = rng.uniform(-1, 1, (3_000, 3))
+    bad_q[::53, 2] = np.nan
+    bad_q[7::61, 0] = -np.inf
+    cases.append(("nonfinite", bad_q, bad_t))
+    for name, q, t in cases:
+        ib, db = icp.nearest_neighbors(q, t, icp.NN_BRUTE)
+        iv, dv = icp.nearest_neighbors(q, t, icp.NN_BVH)
+        assert np.array_equal(iv, ib), name
+        assert np.array_equal(dv, db), name
+    idx, d2 = icp.nearest_neighbors(np.zeros((4, 3)), np.zeros((0, 3)), icp.NN_BVH)
+    assert np.all(idx == 0) and np.all(np.isinf(d2))
+    # two tight clusters far apart: the grid's cell budget leaves each cluster in a handful of cells (degenerate),
+    # so nn = auto goes to the BVH by itself; same answers as the forced modes
+    a = np.concatenate([rng.normal(0.0, 0.004, (30_000, 3)), rng.normal(100.0, 0.004, (30_000, 3))])
+    b = np.concatenate([rng.normal(0.0, 0.004, (30_000, 3)), rng.normal(100.0, 0.004, (30_000, 3))])
+    ia, da = icp.nearest_neighbors(a, b, icp.NN_AUTO)
+    iv, dv = icp.nearest_neighbors(a, b, icp.NN_BVH)
+    ib, db = icp.nearest_neighbors(a, b, icp.NN_BRUTE)
+    assert np.array_equal(ia, ib) and np.array_equal(da, db)
+    assert np.array_equal(iv, ib) and np.array_equal(dv, db)
+    # at BASELINE config 4's size: against the grid on every query, uniform and clustered
+    for clustered in (False, True):
+        src, tgt, _, _ = synth.config4(1_000_000, clustered=clustered)
+        ig, dg = icp.nearest_neighbors(src, tgt, icp.NN_GRID)
+        iv, dv = icp.nearest_neighbors(src, tgt, icp.NN_BVH)
+        assert np.array_equal(iv, ig) and np.array_equal(dv, dg), clustered
 
 
 def test_config4_converge_recovers_known_transform(icp):
