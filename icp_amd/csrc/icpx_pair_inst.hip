@@ -50,7 +50,8 @@ int launch_one(const PairBatch& pb_in, int64_t n_pairs, const PairLaunch& g, hip
             pb.n_pairs = static_cast<int32_t>(n_pairs);
             pb.sched_steps = 1;
             if (const int v = knobs().sched_steps) pb.sched_steps = v;  // development knob ICPX_SCHED_STEPS
-            ICPX_HIP(hipMemsetAsync(pb.sched_state, 0, sizeof(int32_t) * (n_pairs + 1), stream));
+            // (whole 16-byte units: one fill kernel instead of two; the callers reserve twice the words)
+            ICPX_HIP(hipMemsetAsync(pb.sched_state, 0, (sizeof(int32_t) * (n_pairs + 1) + 15) & ~size_t(15), stream));
             pb.sched_done = pb.sched_state + n_pairs;
         } else {
             pb.sched_state = nullptr;
