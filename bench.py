@@ -156,9 +156,10 @@ def main():
             # spans most of the step) and launched alone after the timed region
             "launch_ms": {"3d": k3, "2d": k2, "3d_alone": alone3, "2d_alone": alone2},
             "config": {
-                "workload": "BASELINE config 5 shard per GPU: 512 2D pairs (n=m=1024, trimmed ICP2, "
-                            "overlap 0.9) + 512 3D pairs (n=m=4096, vanilla ICP3), ICPDriver "
-                            "max_iterations=50, transform tolerance (1e-4, 1e-4); results gathered with RCCL",
+                "workload": f"BASELINE config 5 shard per GPU: {sh.p2} 2D pairs (n=m=1024, trimmed ICP2, "
+                            f"overlap 0.9) + {sh.p3} 3D pairs (n=m=4096, vanilla ICP3), ICPDriver "
+                            "max_iterations=50, transform tolerance (1e-4, 1e-4); results gathered with RCCL"
+                            + (f"; strong scaling: {total2} + {total3} pairs in all" if args.pairs_total else ""),
                 "pairs_per_gpu": sh.p2 + sh.p3,
                 "mean_iterations_2d": float(it2.mean()),
                 "mean_iterations_3d": float(it3.mean()),
