@@ -2,8 +2,9 @@
 // include/algo/kdtree.h, compiled from where it lies under /root/reference (never copied).
 // This file is only the C-ABI driver around that header: it instantiates icp::KdTree with a
 // plain POD point type (the header is templated on any PointT with operator[] and size()).
-// TEST INFRASTRUCTURE: used to pin oracle/icp_oracle.cpp's kd-tree restatement and, in
-// bench.py, as the "reference"-kind CPU baseline for the NN step.
+// TEST INFRASTRUCTURE: used to pin oracle/icp_oracle.cpp's kd-tree restatement (tests/test_oracle.py,
+// tests/test_gpu_parity.py::test_nn_against_reference_kdtree_semantics).  bench.py's cpu_baseline times the
+// oracle's own restatement ("port"), not this library.
 #include <array>    // kdtree.h:67 uses std::array without including it
 #include <cstdint>
 #include <vector>
