@@ -279,9 +279,12 @@ ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded
 // returns, bit for bit.  Per-wave LDS staging: CoopStage.  Wave-slots with more candidates than the list
 // holds are searched in lane groups (halves, quarters, ...).
 // ---------------------------------------------------------------------------------------------
+#ifndef ICPX_COOP_BLOCK
+#define ICPX_COOP_BLOCK 2
+#endif
 constexpr int kCoopCap = 512;      // candidates of one pass that fit the flat list (8 steps of 64)
 constexpr int kCoopSteps = kCoopCap / 64;
-constexpr int kCoopBlock = 2;      // steps whose loads are issued together
+constexpr int kCoopBlock = ICPX_COOP_BLOCK;      // steps whose loads are issued together
 
 inline __host__ __device__ size_t coop_wave_bytes(int dim) {
     return static_cast<size_t>(64) * 8 * dim + 64 * 8 + 64 * 4 + 64 * 4 + static_cast<size_t>(kCoopCap + 64) * 4;
