@@ -626,49 +626,10 @@ struct SlotVecI {
     }
 };
 
-template <int D, int QPT>
-ICPX_DEV void pruned_search(const double (&q)[QPT][D], const bool (&valid)[QPT], const bool seeded,
-                            const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, const bool coop,
-                            const int m, double (&best)[QPT], int (&pair)[QPT]) {
-    SlotVec<QPT> qv[D], bv;
-    SlotVecI<QPT> pv;
-    int vmask = 0;
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-#pragma unroll
-        for (int d = 0; d < D; d++) qv[d].d[k] = q[k][d];
-        pv.d[k] = pair[k];
-        bv.d[k] = 0.0;
-        vmask |= valid[k] ? (1 << k) : 0;
-    }
-#pragma unroll 1
-    for (int k = 0; k < QPT; k++) {
-        double q1[1][D];
-#pragma unroll
-        for (int d = 0; d < D; d++) q1[0][d] = qv[d].d[0];
-        const bool v = ((vmask >> k) & 1) != 0;
-        double b1[1] = {0.0};
-        int s1[1] = {pv.d[0]};
-        if (seeded) seed_bound<D, 1>(q1, L, m, b1, s1);
-        if (coop) nn_coop_slot<D>(q1[0], v, seeded, L, P, S, b1[0], s1[0]);
-        else nn_grid_slot<D>(q1[0], v, seeded, L, P, b1[0], s1[0]);
-        bv.d[0] = v ? b1[0] : 0.0;
-        pv.d[0] = v ? s1[0] : 0;
-#pragma unroll
-        for (int d = 0; d < D; d++) qv[d].rotate();
-        bv.rotate();
-        pv.rotate();
-    }
-#pragma unroll
-    for (int k = 0; k < QPT; k++) {
-        best[k] = bv.d[k];
-        pair[k] = pv.d[k];
-    }
-}
-
 // One visit of pair p: optional begin()/setup(), then up to max_steps iterations of the converge
 // loop.  Returns 1 when should_terminate fired (pair finished), 2 when it paused at max_steps.
-template <int D, int METHOD, int QPT, bool PRUNE>
+// (The brute-force body: handles and small clouds.  Batches run pair_body_pruned, icpx_pair_pruned.h.)
+template <int D, int METHOD, int QPT>
 ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps,
                        double* lds_raw) {
     constexpr int L1 = D + 1;
@@ -681,33 +642,13 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     const double* __restrict__ src = pb.src + s0 * D;
     const double* __restrict__ dst = pb.dst + d0 * D;
     PairState* st = pb.states + p;
-    // PRUNE kernels (batches): grid-pruned search, no f32 copy; `filter` then only stands for "the
-    // search is seeded by the previous neighbours"
-    constexpr bool prune = PRUNE;
-    const bool filter = PRUNE || (pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA));
-    LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter && !prune);
+    const bool filter = pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
+    LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
     const bool empty = (n == 0 || m == 0);
-    GridView P;
-    if (prune) {
-        uint16_t* table = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(lds_raw) +
-                                                      pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap));
-        P.g = pb.grids[p];
-        int ncell = P.g.G;
-        for (int d = 1; d < D; d++) ncell *= P.g.G;
-        for (int c = tid; c <= ncell; c += T) table[c] = pb.cstart[static_cast<int64_t>(p) * kGridTable + c];
-        P.cstart = table;
-        P.tperm = pb.tperm + d0;
-        P.m = m;
-    }
-    // per-wave staging of the cooperative search, behind the table
-    CoopStage<D> CS = coop_carve<D>(reinterpret_cast<char*>(lds_raw) +
-                                    pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap) +
-                                    sizeof(uint16_t) * kGridTable + static_cast<size_t>(tid >> 6) * coop_wave_bytes(D));
-    const bool coop = prune && pb.coop != 0;
 
     // ---- stage the target cloud into LDS as SoA (+ f32 copy about the bounding-box centre) ----
     const int m4 = (m + 3) & ~3;
-    const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter && !prune, prune ? P.tperm : nullptr);
+    const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter);
 
     // ---- per-thread point slots ----
     double a[QPT][D];    // 2D: source points; 3D: running cloud c
@@ -783,8 +724,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            if (prune) pruned_search<D, QPT>(q, valid, false, L, P, CS, coop, m, best, pair);
-            else if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
+            if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
             else nn_lds<D, QPT>(q, L, m4, best, pair);
             have_seed = filter;
 #pragma unroll
@@ -866,9 +806,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
-                    if (prune) {
-                        pruned_search<D, QPT>(cur, valid, have_seed, L, P, CS, coop, m, best, pair);
-                    } else if (have_seed) {
+                    if (have_seed) {
                         seed_bound<D, QPT>(cur, L, m, best, pair);
                         nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
                     } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
@@ -909,9 +847,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++)
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
-                if (prune) {
-                    pruned_search<D, QPT>(cur, valid, have_seed, L, P, CS, coop, m, best, pair);
-                } else if (have_seed) {
+                if (have_seed) {
                     seed_bound<D, QPT>(cur, L, m, best, pair);
                     nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
                 } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
@@ -1014,7 +950,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 #pragma unroll
             for (int k = 0; k < QPT; k++)
                 if (valid[k]) {
-                    pb.m_pair[s0 + tid + k * T] = prune ? static_cast<int>(P.tperm[pair[k]]) : pair[k];
+                    pb.m_pair[s0 + tid + k * T] = pair[k];
                     pb.m_cost[s0 + tid + k * T] = cost[k];
                     pb.m_point[s0 + tid + k * T] = tid + k * T;
                 }
@@ -1023,7 +959,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             for (int k = 0; k < QPT; k++)
                 if (valid[k]) {
                     pb.m_point[s0 + tid + k * T] = tid + k * T;
-                    pb.m_pair[s0 + tid + k * T] = prune ? static_cast<int>(P.tperm[pair[k]]) : pair[k];
+                    pb.m_pair[s0 + tid + k * T] = pair[k];
                     pb.m_cost[s0 + tid + k * T] = cost[k];
                 }
         } else {
@@ -1038,7 +974,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             for (int k = 0; k < QPT; k++)
                 if (valid[k]) {
                     L.skey[tid + k * T] = static_cast<uint64_t>(__double_as_longlong(cost[k]));
-                    pb.pair_tmp[s0 + tid + k * T] = prune ? static_cast<int>(P.tperm[pair[k]]) : pair[k];
+                    pb.pair_tmp[s0 + tid + k * T] = pair[k];
                 }
             __syncthreads();
             bitonic_sort(L.skey, L.sval, npad, T);
@@ -1080,7 +1016,7 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p, const int do_set
 template <int D, int METHOD, int QPT, bool PRUNE>
 ICPX_DEV int pair_visit(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps, double* lds_raw) {
     if constexpr (PRUNE) return pair_body_pruned<D, METHOD, QPT>(pb, p, do_setup, max_steps, lds_raw);
-    else return pair_body<D, METHOD, QPT, false>(pb, p, do_setup, max_steps, lds_raw);
+    else return pair_body<D, METHOD, QPT>(pb, p, do_setup, max_steps, lds_raw);
 }
 
 template <int D, int METHOD, int QPT, int TMAX, bool PRUNE>
