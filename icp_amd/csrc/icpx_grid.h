@@ -331,7 +331,69 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
         for (int d = 0; d < D; d++)
             slack[d] = (dabs(gp.lo[d]) + dabs(gp.hi[d]) + dabs(q[d])) * 2.8421709430404007e-14;  // 2^-45
         const int gx = gp.g[0], gy = gp.g[1], gz = D == 3 ? gp.g[2] : 1;
-        for (int r = r0; r <= gp.rmax; r++) {
+        int r_begin = r0;
+        if (r0 == 0 && gp.rmax >= 1) {
+            // Shells 0 and 1 together — the 3^D cells around the query, almost always all it needs: the bounds of their
+            // (up to 9) rows are fetched FIRST, as independent loads, and only then the records row by row; shell by
+            // shell every row costs two dependent round trips before its first record arrives (the walk is a chain of
+            // L2 latencies: 261 -> ... us on config 4).  Same cells, same (d2, index) rule, the stopping test of shell 1.
+            constexpr int NR = D == 3 ? 9 : 3;
+            const int xlo = c[0] - 1 > 0 ? c[0] - 1 : 0, xhi = c[0] + 1 < gx - 1 ? c[0] + 1 : gx - 1;
+            int kb[NR], ke[NR];
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                const int y = c[1] - 1 + t % 3, z = D == 3 ? c[2] - 1 + t / 3 : 0;
+                const bool in = y >= 0 && y < gy && z >= 0 && z < gz;
+                const int row = in ? (z * gy + y) * gx : 0;
+                kb[t] = start[row + xlo];
+                ke[t] = in ? start[row + xhi + 1] : kb[t];
+            }
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                for (int k0 = kb[t]; k0 < ke[t]; k0 += 4) {
+                    GridRec rec[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rec[u] = recs[k0 + u < ke[t] ? k0 + u : ke[t] - 1];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        double df = rec[u].x - q[0];
+                        double dist = df * df;
+                        df = rec[u].y - q[1];
+                        dist = dist + df * df;
+                        if (D == 3) {
+                            df = rec[u].z - q[2];
+                            dist = dist + df * df;
+                        }
+                        const int j = static_cast<int>(rec[u].idx);
+                        const bool take = (k0 + u < ke[t]) && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
+                        best = take ? dist : best;
+                        bidx = take ? j : bidx;
+                    }
+                }
+                visited += ke[t] - kb[t];
+            }
+            // the stopping test after shell 1 (as at the end of the loop below)
+            double lb = __builtin_inf();
+            bool all_covered = true;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int kl = c[d] - 1, kh = c[d] + 2;
+                if (kl > 0) {
+                    all_covered = false;
+                    double gap = (q[d] - (gp.lo[d] + static_cast<double>(kl) * gp.h[d])) - slack[d];
+                    gap = gap > 0.0 ? gap : 0.0;
+                    lb = gap < lb ? gap : lb;
+                }
+                if (kh < gp.g[d]) {
+                    all_covered = false;
+                    double gap = ((gp.lo[d] + static_cast<double>(kh) * gp.h[d]) - q[d]) - slack[d];
+                    gap = gap > 0.0 ? gap : 0.0;
+                    lb = gap < lb ? gap : lb;
+                }
+            }
+            r_begin = (all_covered || best < lb * lb * 0.99999999999909051) ? gp.rmax + 1 : 2;
+        }
+        for (int r = r_begin; r <= gp.rmax; r++) {
             if (r >= 2 && best < __builtin_inf()) {
                 // shells 0 and 1 did not settle it: the rest through the ball of the candidate
                 grid_ball_scan<D>(gp, recs, start, q, c, best, bidx, visited);
