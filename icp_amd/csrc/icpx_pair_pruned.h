@@ -197,6 +197,9 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
     if (do_setup) {
         if (D == 2 && !empty) {
             int dummy;
+#ifdef ICPX_PROBE
+            if (!(pb.coop & 256))
+#endif
             search(false, dummy);
             have_seed = true;
         }

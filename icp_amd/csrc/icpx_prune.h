@@ -550,6 +550,69 @@ ICPX_DEV bool coop_box(const double (&q)[D], const bool act, const int (&c0)[D],
     return mine;
 }
 
+// Large boxes (more than 3 x 3 rows, an overfull list, no bound yet = every cell): one such query at a time, ALL
+// lanes of the wave scan for it.  A single lane walking its box alone is a chain of dependent LDS round trips — a
+// query with no target in its 3^D cells walked all m targets that way (130 us for 1024 targets, the whole
+// workgroup waiting: the tail of the 2D setup search) — 64 lanes take 64 targets per step.  They scan the RUN of
+// slots from the box's first cell to its last (cells are in x-fastest order): a superset of the box's targets,
+// which is as good (everything at most as far as the bound is inside the box, hence inside the run).
+// (best, bslot) of the lanes in `walk`: running lexicographic minimum of (d2, cloud index), bslot < 0 = none yet.
+template <int D>
+ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w0)[D], const int (&w1)[D],
+                            const LdsView<D>& L, const GridView& P, double& best, int& bslot) {
+    const int lane = threadIdx.x & 63;
+    const int G = P.g.G;
+    int first = 0, last = 0;
+#pragma unroll
+    for (int d = D - 1; d >= 0; d--) {
+        first = first * G + w0[d];
+        last = last * G + w1[d];
+    }
+    unsigned long long todo = __ballot(walk);
+    while (todo) {
+        const int src = __ffsll(static_cast<long long>(todo)) - 1;
+        todo &= todo - 1;
+        double qq[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) qq[d] = __shfl(q[d], src);
+        const int kb = P.cstart[__shfl(first, src)], ke = P.cstart[__shfl(last, src) + 1];
+        double mb = __builtin_inf();
+        int ms = -1;
+        for (int j = kb + lane; j < ke; j += 64) {
+            double df = L.t[0][j] - qq[0];
+            double acc = df * df;
+#pragma unroll
+            for (int d = 1; d < D; d++) {
+                df = L.t[d][j] - qq[d];
+                acc = acc + df * df;
+            }
+            bool better = acc < mb;
+            if (acc == mb && ms >= 0) better = P.tperm[j] < P.tperm[ms];
+            mb = better ? acc : mb;
+            ms = better ? j : ms;
+        }
+        // lexicographic minimum over the lanes
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ob = __shfl_xor(mb, o);
+            const int os = __shfl_xor(ms, o);
+            bool take = os >= 0 && (ms < 0 || ob < mb);
+            const bool tie = os >= 0 && ms >= 0 && ob == mb && os != ms;
+            if (__any(tie)) {
+                if (tie) take = P.tperm[os] < P.tperm[ms];
+            }
+            mb = take ? ob : mb;
+            ms = take ? os : ms;
+        }
+        if (lane == src && ms >= 0) {
+            bool take = bslot < 0 || mb < best;
+            if (bslot >= 0 && mb == best && ms != bslot) take = P.tperm[ms] < P.tperm[bslot];
+            best = take ? mb : best;
+            bslot = take ? ms : bslot;
+        }
+    }
+}
+
 template <int D>
 ICPX_DEV bool box_inside(const int (&a0)[D], const int (&a1)[D], const int (&b0)[D], const int (&b1)[D]) {
     bool in = true;
@@ -627,8 +690,8 @@ ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded
                 w1[d] = r1[d];
             }
             if (stage < 2) grid_range<D>(q, best, P.g, w0, w1);  // (a local block that overflowed the list)
-            grid_walk<D>(q, walk, w0, w1, L, P, best, bslot);
-            ICPX_CYC(24);  // per-lane walk of the large boxes
+            coop_run_scan<D>(q, walk, w0, w1, L, P, best, bslot);
+            ICPX_CYC(24);  // the large boxes, one query at a time, the wave scanning together
         }
         if (act && taken) {
             if (stage == 2) {
