@@ -38,23 +38,27 @@ class Config5Shard:
         self.st2 = torch.cuda.Stream(self.dev)
         self.st3 = torch.cuda.Stream(self.dev)
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self.ev_begin = torch.cuda.Event()
 
     def step(self, timed: bool = False):
         """One pass of the hot path over the shard; results in self.out, ordered on the current stream."""
         torch = self.torch
         cur = torch.cuda.current_stream(self.dev)
-        self.st2.wait_stream(cur)
-        self.st3.wait_stream(cur)
-        # the 2D launch first: its pairs are latency-bound (a chain of short iterations, two workgroups per compute
-        # unit) and finish at very different times; the persistent 3D workgroups need a whole compute unit each
-        # and start on the units the 2D pairs leave, taking their tasks from the 3D launch's queue
+        # The 2D launch goes first and on the caller's stream: its pairs are latency-bound (a chain of short iterations,
+        # two workgroups per compute unit) and finish at very different times; the persistent 3D workgroups need a whole
+        # compute unit each, start on the units the 2D pairs leave and take their tasks from the 3D launch's queue.
+        # The 3D launch runs on a second stream that waits for what was on the caller's stream BEFORE this step (not
+        # for the 2D launch), and the caller's stream joins it at the end: one cross-stream hand-over per step.
+        self.ev_begin.record(cur)
+        if self.p3:
+            self.st3.wait_event(self.ev_begin)
         if self.p2:
             if timed:
-                self.ev[2].record(self.st2)
+                self.ev[2].record(cur)
             api.converge_batch(2, "trimmed", self.d_s2, self.off2, self.d_t2, self.off2, self.crit,
-                               out_states=self.out[:self.p2], device=self.device, stream=self.st2.cuda_stream)
+                               out_states=self.out[:self.p2], device=self.device, stream=cur.cuda_stream)
             if timed:
-                self.ev[3].record(self.st2)
+                self.ev[3].record(cur)
         if self.p3:
             if timed:
                 self.ev[0].record(self.st3)
@@ -62,8 +66,7 @@ class Config5Shard:
                                out_states=self.out[self.p2:], device=self.device, stream=self.st3.cuda_stream)
             if timed:
                 self.ev[1].record(self.st3)
-        cur.wait_stream(self.st2)
-        cur.wait_stream(self.st3)
+            cur.wait_stream(self.st3)
 
     def launch_ms(self):
         """(3D launch, 2D launch) durations of the last timed step, HIP events on the launch streams."""
@@ -81,7 +84,7 @@ class Config5Shard:
             return 0.0
         torch.cuda.synchronize(self.dev)
         ms = []
-        for _ in range(reps):
+        for rep in range(reps + 1):  # (the first one, untimed, creates the stream's workspace)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(st)
             if dim == 3:
@@ -92,7 +95,8 @@ class Config5Shard:
                                    out_states=self.out[:self.p2], device=self.device, stream=st.cuda_stream)
             b.record(st)
             st.synchronize()
-            ms.append(a.elapsed_time(b))
+            if rep:
+                ms.append(a.elapsed_time(b))
         return float(np.mean(ms))
 
     def states(self):
