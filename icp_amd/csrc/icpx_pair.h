@@ -16,6 +16,9 @@
 // fits LDS (checked on the host, icpx_capi.hip).  Larger clouds take the multi-kernel path.
 #pragma once
 
+#ifndef ICPX_SELECT_BITS
+#define ICPX_SELECT_BITS 10
+#endif
 #ifndef ICPX_3D_SMALL_WAVES
 #define ICPX_3D_SMALL_WAVES 3
 #endif
@@ -243,19 +246,21 @@ ICPX_DEV uint32_t wave_or_u32(uint32_t v) {
 // and its point, so that the pairs <= (kth, vth) are exactly the first `rank` of the sorted sequence.  Replaces
 // the full sort in Trimmed::iterate (trimmed.cpp:55-58): only the threshold is needed to mark the kept matches.
 //   1. the bits the valid keys do not share (AND / OR over the workgroup): the digits above them are skipped;
-//   2. MSB-first radix passes with 8-bit digits from the first differing bit down (LDS histogram, wave-0 scan;
+//   2. MSB-first radix passes with ICPX_SELECT_BITS-bit digits from the first differing bit down (LDS histogram, wave-0 scan;
 //      after the key's bits, the point's), until at most 64 pairs are left in the rank's bucket;
 //   3. those pairs go into a list and every wave ranks them directly.
 // Positive doubles of one cloud share their leading digits, and 8 bits divide ~1000 pairs into buckets of a few:
-// typically two passes.  Workgroup-wide (barriers); hist: >= 512 ints of LDS; points must be below 65536.
+// typically two passes.  Workgroup-wide (barriers); hist: >= 2^ICPX_SELECT_BITS + 232 ints of LDS (kGsValues * kGsStride
+// doubles = 1280 ints are there); points must be below 65536.
 template <int QPT>
 ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT], int T, int rank, int* hist,
                            uint64_t& kth, uint32_t& vth) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
-    int* res = hist + 256;                                               // [0] digit, [1] rank inside, [2] bucket size, [4] list length
-    uint64_t* lkey = reinterpret_cast<uint64_t*>(hist + 264);           // 64 keys
-    uint32_t* lpt = reinterpret_cast<uint32_t*>(hist + 392);            // 64 points
-    uint32_t* wred = reinterpret_cast<uint32_t*>(hist + 456);           // per wave: and_lo, and_hi, or_lo, or_hi
+    constexpr int kBits = ICPX_SELECT_BITS, kBins = 1 << kBits, kPer = kBins / 64;
+    int* res = hist + kBins;                                             // [0] digit, [1] rank inside, [2] bucket size, [4] list length
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(hist + kBins + 8);     // 64 keys
+    uint32_t* lpt = reinterpret_cast<uint32_t*>(hist + kBins + 136);    // 64 points
+    uint32_t* wred = reinterpret_cast<uint32_t*>(hist + kBins + 200);   // per wave: and_lo, and_hi, or_lo, or_hi
     bool act[QPT];
     uint32_t alo = 0xffffffffu, ahi = 0xffffffffu, olo = 0, ohi = 0;
 #pragma unroll
@@ -277,7 +282,7 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
         wred[wave * 4 + 2] = olo;
         wred[wave * 4 + 3] = ohi;
     }
-    for (int i = tid; i < 256; i += T) hist[i] = 0;
+    for (int i = tid; i < kBins; i += T) hist[i] = 0;
     if (tid == 0) res[4] = 0;
     __syncthreads();
     for (int w = 0; w < W; w++) {
@@ -289,30 +294,30 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
     const uint64_t differ = (static_cast<uint64_t>(ahi ^ ohi) << 32) | (alo ^ olo);  // (no valid key: all ones; rank is 0 then)
     // digit windows: `shift` = low bit of the window, in the key while on_key, then in the point
     bool on_key = differ != 0;
-    int shift = on_key ? max(63 - __builtin_clzll(differ) - 7, 0) : 8;
+    int shift = on_key ? max(63 - __builtin_clzll(differ) - (kBits - 1), 0) : 8;
     int remaining = rank;
     for (int pass = 0; pass < 12; pass++) {
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
             const uint32_t point = static_cast<uint32_t>(tid + k * T);
-            const int d = on_key ? static_cast<int>((key[k] >> shift) & 255) : static_cast<int>((point >> shift) & 255);
+            const int d = on_key ? static_cast<int>((key[k] >> shift) & (kBins - 1)) : static_cast<int>((point >> shift) & 255);
             if (act[k]) atomicAdd(&hist[d], 1);
         }
         __syncthreads();
         if (tid < 64) {
-            int c[4], s = 0;
+            int c[kPer], s = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                c[u] = hist[4 * lane + u];
-                hist[4 * lane + u] = 0;  // for the next pass
+            for (int u = 0; u < kPer; u++) {
+                c[u] = hist[kPer * lane + u];
+                hist[kPer * lane + u] = 0;  // for the next pass
                 s += c[u];
             }
             const int incl = wave_incl_scan(s);
             int excl = incl - s;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kPer; u++) {
                 if (excl < remaining && remaining <= excl + c[u]) {
-                    res[0] = 4 * lane + u;
+                    res[0] = kPer * lane + u;
                     res[1] = remaining - excl;
                     res[2] = c[u];
                 }
@@ -326,7 +331,7 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
             const uint32_t point = static_cast<uint32_t>(tid + k * T);
-            const int dk = on_key ? static_cast<int>((key[k] >> shift) & 255) : static_cast<int>((point >> shift) & 255);
+            const int dk = on_key ? static_cast<int>((key[k] >> shift) & (kBins - 1)) : static_cast<int>((point >> shift) & 255);
             act[k] = act[k] && dk == d;
         }
         if (bucket <= 64) break;
@@ -336,7 +341,7 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
                 on_key = false;
                 shift = 8;
             } else {
-                shift = max(shift - 8, 0);
+                shift = max(shift - kBits, 0);
             }
         } else {
             shift = 0;

@@ -8,7 +8,7 @@ from icp_amd import synth
 lib = icp_amd._lib.load()
 s, t, off, _ = synth.config5_pairs(np.arange(512), 3, 4096)
 crit = icp_amd.make_criteria(max_iterations=50, transform_tol=(1e-4, 1e-4))
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 32)()
 icp_amd.converge_batch(3, "vanilla", s, off, t, off, crit, device=0)
 lib.icpx_debug_stats(out, 1)
 _, it, _ = icp_amd.converge_batch(3, "vanilla", s, off, t, off, crit, device=0)
