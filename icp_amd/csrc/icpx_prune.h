@@ -279,6 +279,9 @@ ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded
 // returns, bit for bit.  Per-wave LDS staging: CoopStage.  Wave-slots with more candidates than the list
 // holds are searched in lane groups (halves, quarters, ...).
 // ---------------------------------------------------------------------------------------------
+#ifndef ICPX_LIST_STRIDED
+#define ICPX_LIST_STRIDED 1
+#endif
 #ifndef ICPX_RESOLVE_MASKED
 #define ICPX_RESOLVE_MASKED 0
 #endif
@@ -397,6 +400,7 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
         dk[c] = ~0ull;
         ent[c] = tag;
     }
+    const int nsteps = (base + 63) >> 6;  // uniform
 #pragma unroll
     for (int cb = 0; cb < kCoopSteps; cb += kCoopBlock) {
         if (cb * 64 < base) {  // uniform
@@ -404,8 +408,15 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
             bool on[kCoopBlock];
 #pragma unroll
             for (int u = 0; u < kCoopBlock; u++) {
+#if ICPX_LIST_STRIDED
+                // lane l takes entries l * nsteps + step: a query's candidates are neighbours in the list, and this way
+                // they meet in different steps instead of hitting the query's accumulator in one LDS atomic instruction
+                const int i = lane * nsteps + (cb + u);
+                on[u] = (cb + u) < nsteps && i < base;
+#else
                 const int i = (cb + u) * 64 + lane;
                 on[u] = i < base;
+#endif
                 e[u] = S.list[on[u] ? i : dump];
             }
             double tq[kCoopBlock][D], tt[kCoopBlock][D];
