@@ -1044,6 +1044,11 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
     return ICPX_OK;
 }
 
+// rocPRIM sorts up to 2^20 items by block sort + ~log2(n / 1024) merge passes; for keys of few bits the one-sweep
+// radix sort (one pass per 8 bits) is the shorter chain of kernels, so it is asked for whatever the size.
+using OneSweepAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::default_config, 0>;
+
 // Orders the queries by the grid cell they fall in (stable radix sort of the cell ids): the query
 // kernels then visit them in that order.  Worth it from a few 10^4 queries on.
 int grid_sort_queries(GridIndex* g, const double* d_q, int64_t n, hipStream_t stream) {
@@ -1068,13 +1073,13 @@ int grid_sort_queries(GridIndex* g, const double* d_q, int64_t n, hipStream_t st
     int bits = 1;
     while (bits < 32 && (int64_t(1) << bits) < max_key) bits++;
     size_t bytes = 0;
-    ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, g->q_keys.as<uint32_t>(), g->q_keys_out.as<uint32_t>(),
-                                                g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(), static_cast<int>(n), 0,
-                                                bits, stream));
+    ICPX_HIP(rocprim::radix_sort_pairs<OneSweepAlways>(nullptr, bytes, g->q_keys.as<uint32_t>(), g->q_keys_out.as<uint32_t>(),
+                                                       g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(),
+                                                       static_cast<unsigned>(n), 0u, static_cast<unsigned>(bits), stream));
     ICPX_TRY(g->q_tmp.reserve(bytes ? bytes : 1));
-    ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(g->q_tmp.p, bytes, g->q_keys.as<uint32_t>(), g->q_keys_out.as<uint32_t>(),
-                                                g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(), static_cast<int>(n), 0,
-                                                bits, stream));
+    ICPX_HIP(rocprim::radix_sort_pairs<OneSweepAlways>(g->q_tmp.p, bytes, g->q_keys.as<uint32_t>(), g->q_keys_out.as<uint32_t>(),
+                                                       g->q_iota.as<uint32_t>(), g->q_perm.as<uint32_t>(),
+                                                       static_cast<unsigned>(n), 0u, static_cast<unsigned>(bits), stream));
     g->q_perm_n = n;
     // ranges of the sorted order that fall into each block of four tiles (block-cooperative query)
     g->q_blocks = static_cast<int64_t>(nt[0] >> 2) * nt[1] * nt[2];
