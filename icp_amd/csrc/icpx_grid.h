@@ -240,6 +240,51 @@ __global__ void grid_scatter_kernel(const double* __restrict__ t, int64_t m, con
     recs[pos] = r;
 }
 
+// The records of NR rows of cells, [kb[t], ke[t]) each, against one query, as ONE sequence, four records per step:
+// record r of the sequence is record r - pre[t] of the row t with pre[t] <= r < pre[t + 1].  A lane's records are
+// spread over several short rows, and row by row every row costs the wave a memory round trip of its own (config 4
+// converge 16.3 -> 14.3 ms).  (best, bidx): running (d2, index) minimum; bidx = 0x7fffffff while there is none.
+template <int D, int NR>
+ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, const int (&kb)[NR], const int (&ke)[NR],
+                             double& best, int& bidx, int& visited) {
+    constexpr int kStep = 4;  // records in flight per lane (8: more registers, fewer waves, no gain — measured)
+    int pre[NR], off[NR];
+    int total = 0;
+#pragma unroll
+    for (int t = 0; t < NR; t++) {
+        pre[t] = total;
+        off[t] = kb[t] - total;
+        total += ke[t] - kb[t];
+    }
+    for (int r0 = 0; r0 < total; r0 += kStep) {
+        GridRec rec[kStep];
+#pragma unroll
+        for (int u = 0; u < kStep; u++) {
+            const int r = r0 + u < total ? r0 + u : total - 1;
+            int o = off[0];
+#pragma unroll
+            for (int t = 1; t < NR; t++) o = r >= pre[t] ? off[t] : o;
+            rec[u] = recs[r + o];
+        }
+#pragma unroll
+        for (int u = 0; u < kStep; u++) {
+            double df = rec[u].x - q[0];
+            double dist = df * df;
+            df = rec[u].y - q[1];
+            dist = dist + df * df;
+            if (D == 3) {
+                df = rec[u].z - q[2];
+                dist = dist + df * df;
+            }
+            const int j = static_cast<int>(rec[u].idx);
+            const bool take = (r0 + u < total) && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
+            best = take ? dist : best;
+            bidx = take ? j : bidx;
+        }
+    }
+    visited += total;
+}
+
 // Continuation of a query that has a finite candidate (best, bidx) and has not met the shells' stopping test:
 // instead of more shells (whose cell count grows with the cube of the distance — queries outside the target's
 // box, sparse regions), only the rows of cells that the BALL of the current best can reach are visited, and in
@@ -308,6 +353,61 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ r
     }
 }
 
+// A query that starts from a candidate — its neighbour of the previous correspondence step, (best, bidx) with best
+// finite and the query finite.  The answer lies in the ball of that candidate, which late in a converge is a
+// fraction of the 3^D cells grid_query opens: rows of the ball's cell box (at most 3 x 3, else grid_ball_scan) are
+// tested and bounded exactly as in grid_ball_scan, but all their bounds are fetched before the first record (the
+// walk is a chain of memory latencies).  The candidate itself is among the visited targets, so the result is the
+// (d2, index) minimum over the whole cloud: what grid_query returns.
+template <int D>
+ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+                                const double* q, double& best, int& bidx, int& visited) {
+    int c[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < D; d++) c[d] = cell_coord<D>(gp, q[d], d);
+    const double down = 0.99999999999909051;  // 1 - 2^-40
+    double slack[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < D; d++) slack[d] = (dabs(gp.lo[d]) + dabs(gp.hi[d]) + dabs(q[d])) * 2.8421709430404007e-14;  // 2^-45
+    auto gap_of = [&](int d, int k) -> double {
+        double g = 0.0;
+        if (k > c[d]) g = (gp.lo[d] + static_cast<double>(k) * gp.h[d]) - q[d] - slack[d];
+        else if (k < c[d]) g = q[d] - (gp.lo[d] + static_cast<double>(k + 1) * gp.h[d]) - slack[d];
+        return g > 0.0 ? g : 0.0;
+    };
+    auto range_of = [&](int d, double rad, int& k0, int& k1) {
+        const double r = rad * (1.0 + 1.7763568394002505e-15) + 1e-150;  // (1 + 2^-49)
+        const double w = (dabs(q[d]) + r) * 4.4408920985006262e-16;      // 2^-51
+        k0 = cell_coord<D>(gp, q[d] - r - w, d);
+        k1 = cell_coord<D>(gp, q[d] + r + w, d);
+    };
+    const double rad = __builtin_sqrt(best);
+    int z0 = 0, z1 = 0, y0, y1;
+    if (D == 3) range_of(2, rad, z0, z1);
+    range_of(1, rad, y0, y1);
+    if (z1 - z0 > 2 || y1 - y0 > 2) {
+        grid_ball_scan<D>(gp, recs, start, q, c, best, bidx, visited);
+        return;
+    }
+    constexpr int NR = D == 3 ? 9 : 3;
+    const double best_in = best;
+    int kb[NR], ke[NR];
+#pragma unroll
+    for (int t = 0; t < NR; t++) {
+        const int y = y0 + t % 3, z = z0 + t / 3;
+        bool in = y <= y1 && z <= z1;
+        const double gz = D == 3 ? gap_of(2, in ? z : c[2]) : 0.0, gy = gap_of(1, in ? y : c[1]);
+        const double far2 = (gz * gz + gy * gy) * down;
+        in = in && !(far2 > best_in);
+        int x0 = 0, x1 = 0;
+        range_of(0, __builtin_sqrt(in ? best_in - far2 + best_in * 9.0949470177292824e-13 : 0.0), x0, x1);  // as grid_ball_scan
+        const int row = in ? (z * gp.g[1] + y) * gp.g[0] : 0;
+        kb[t] = start[row + x0];
+        ke[t] = in ? start[row + x1 + 1] : kb[t];
+    }
+    grid_scan_rows<D, NR>(recs, q, kb, ke, best, bidx, visited);
+}
+
 // one query against the grid.  Returns (best d2, lowest index among equal d2); (inf, 0) when no
 // target has a finite distance.
 // (r0, best0, bidx0): the shells below r0 have been visited already, with this result (grid_block_query)
@@ -348,30 +448,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                 kb[t] = start[row + xlo];
                 ke[t] = in ? start[row + xhi + 1] : kb[t];
             }
-#pragma unroll
-            for (int t = 0; t < NR; t++) {
-                for (int k0 = kb[t]; k0 < ke[t]; k0 += 4) {
-                    GridRec rec[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) rec[u] = recs[k0 + u < ke[t] ? k0 + u : ke[t] - 1];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        double df = rec[u].x - q[0];
-                        double dist = df * df;
-                        df = rec[u].y - q[1];
-                        dist = dist + df * df;
-                        if (D == 3) {
-                            df = rec[u].z - q[2];
-                            dist = dist + df * df;
-                        }
-                        const int j = static_cast<int>(rec[u].idx);
-                        const bool take = (k0 + u < ke[t]) && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
-                        best = take ? dist : best;
-                        bidx = take ? j : bidx;
-                    }
-                }
-                visited += ke[t] - kb[t];
-            }
+            grid_scan_rows<D, NR>(recs, q, kb, ke, best, bidx, visited);
             // the stopping test after shell 1 (as at the end of the loop below)
             double lb = __builtin_inf();
             bool all_covered = true;

@@ -98,6 +98,7 @@ struct LargeIcp {
     GridIndex* grid = nullptr;
     BvhIndex* bvh = nullptr;   // built instead of / after the grid: nn = bvh, or nn = auto with a degenerate grid
     bool use_bvh = false;
+    bool nn_seeded = false;  // nb_idx holds the neighbours of an earlier correspondence step of this begin()
     DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
     // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
     DevBuf sort_keys, sort_iota, sort_order, sort_tmp;
@@ -161,7 +162,8 @@ __global__ void __launch_bounds__(256)
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
-             double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh) {
+             double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh,
+             const double* __restrict__ seed_tgt) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     if (respect_done && dev->st.done) return;
     // the query of point i as the method defines it
@@ -238,6 +240,29 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     double q[D], best;
     int bi;
     query_of(i, q);
+    if (seed_tgt) {
+        // nb_idx holds the neighbour of the previous correspondence step (the target cloud is seed_tgt): a candidate
+        // whose ball bounds the search (grid_query_seeded).  Same (d2, index) minimum as the unseeded query.
+        const int64_t s = nb_idx[i];
+        bool ok = gp.m > 0;
+        double df = seed_tgt[s * D] - q[0];
+        double d2s = df * df;
+#pragma unroll
+        for (int d = 1; d < D; d++) {
+            df = seed_tgt[s * D + d] - q[d];
+            d2s = d2s + df * df;
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) ok = ok && finite_d(q[d]);
+        ok = ok && d2s < __builtin_inf();  // (false for NaN)
+        if (ok) {
+            best = d2s;
+            bi = static_cast<int>(s);
+            grid_query_seeded<D>(gp, recs, start, q, best, bi, visited);
+            publish(i, best, bi);
+            return;
+        }
+    }
     grid_query<D>(gp, recs, start, q, best, bi, visited);
     publish(i, best, bi);
 }
@@ -1448,7 +1473,7 @@ int enqueue_nn(LargeIcp* lg, int respect) {
             hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), sizeof(float) * 6 * kBvhTopNodes, lg->stream, dev,
                                respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, GridParams{}, nullptr, nullptr,
                                lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance,
-                               bv->q_perm_n == lg->n ? bv->q_perm.as<uint32_t>() : nullptr, nullptr, bv->view());
+                               bv->q_perm_n == lg->n ? bv->q_perm.as<uint32_t>() : nullptr, nullptr, bv->view(), nullptr);
             ICPX_HIP(hipGetLastError());
             return ICPX_OK;
         }
@@ -1462,8 +1487,10 @@ int enqueue_nn(LargeIcp* lg, int respect) {
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, g->gp,
                            g->recs.as<GridRec>(), g->start.as<int>(), lg->nb_idx.as<int64_t>(),
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, perm,
-                           blk ? g->q_start.as<int>() : nullptr, BvhView{});
+                           blk ? g->q_start.as<int>() : nullptr, BvhView{},
+                           (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr);
         ICPX_HIP(hipGetLastError());
+        lg->nn_seeded = true;  // nb_idx now holds this step's neighbours
         return ICPX_OK;
     }
     if (MODE == 0) {
@@ -1621,6 +1648,7 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     // correspondence engine: tiled brute force for mid-size clouds, the uniform grid beyond
     // (ICPX_NN_GRID / ICPX_NN_BRUTE force one or the other)
     lg->use_bvh = false;
+    lg->nn_seeded = false;
     lg->tile = lg->feature || lg->prm.nn_mode == ICPX_NN_BRUTE ||
                (lg->prm.nn_mode != ICPX_NN_GRID && lg->prm.nn_mode != ICPX_NN_BVH &&
                 static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));

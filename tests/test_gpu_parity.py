@@ -932,3 +932,67 @@ def test_config4_converge_recovers_known_transform(icp):
     T = np.eye(4)
     T[:3, :3], T[:3, 3] = R, t
     assert np.abs(r1.transform @ T - np.eye(4)).max() < 0.5 * np.abs(T - np.eye(4)).max()
+
+
+def test_grid_seeded_query_is_bit_identical(icp, ob, knob):
+    """From the second correspondence step of a begin() on, the HBM grid's per-lane query starts from the previous
+    step's neighbour and searches only its ball (grid_query_seeded); ICPX_GRID_SEED=0 keeps the unseeded query.  Both
+    must give the same converge bit for bit — transforms, cost, every neighbour and distance — on uniform and
+    clustered clouds, a lattice (every distance tied many times, the seed is one of the tied targets), sources far
+    outside the targets' box (large balls: the general ball scan), non-finite points, 2D trimmed; and the oracle's
+    result at a size it covers."""
+    from icp_amd import synth
+    rng = np.random.default_rng(31)
+    cases = []
+    src, tgt, _, _ = synth.config4(300_000)
+    cases.append(("config4", 3, "vanilla", src, tgt, False))
+    src, tgt, _, _ = synth.config4(200_000, clustered=True)
+    cases.append(("clustered", 3, "trimmed", src, tgt, False))
+    lat = np.stack(np.meshgrid(np.arange(24.0), np.arange(24.0), np.arange(24.0), indexing="ij"), -1).reshape(-1, 3)
+    cases.append(("lattice", 3, "vanilla", lat[rng.permutation(len(lat))][:9_000] + 0.5, lat, True))
+    cases.append(("outside", 3, "vanilla", rng.uniform(-10, 10, (20_000, 3)) + 25.0, rng.uniform(-10, 10, (30_000, 3)), False))
+    bad_t = rng.uniform(-1, 1, (9_000, 3))
+    bad_t[::97, 1] = np.nan
+    bad_q = rng.uniform(-1, 1, (8_000, 3))
+    bad_q[::53, 2] = np.nan
+    bad_q[7::61, 0] = -np.inf
+    cases.append(("nonfinite-targets", 3, "vanilla", rng.uniform(-1, 1, (8_000, 3)), bad_t, False))
+    s2, t2, _, _ = synth.config5_pairs([14_000], 2, 8_000)
+    cases.append(("2d", 2, "trimmed", s2[:6_000], t2[:8_000], True))
+    crit = dict(max_iterations=7, transform_tol=(1e-9, 1e-9))
+    for name, dim, method, s, t, oracle in cases:
+        out = []
+        for env in ("1", "0"):
+            knob.set("ICPX_GRID_SEED", env)
+            cfg = icp.Config()
+            cfg.set("nn", "grid")
+            cfg.set("max_distance", 0.35)
+            d = driver(icp, icp.ICP2 if dim == 2 else icp.ICP3, method, crit, cfg)
+            r = d.converge(s, t)
+            nb = d.icp_.debug_neighbors() if dim == 3 else d.icp_.get_matches_arrays()
+            out.append((r.iteration_count, r.transform.copy(), r.cost, [np.array(u) for u in nb]))
+        knob.reset("ICPX_GRID_SEED")
+        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]), name
+        assert out[0][2] == out[1][2] or (np.isnan(out[0][2]) and np.isnan(out[1][2])), name
+        for u, v in zip(out[0][3], out[1][3]):
+            assert np.array_equal(u, v, equal_nan=True), name
+        if oracle:
+            ro = dev_oracle(ob, dim, method, max_distance=0.35).converge(s, t, None, ob.make_criteria(**crit))
+            assert out[0][0] == ro.iteration_count and np.array_equal(out[0][1], ro.transform) and out[0][2] == ro.cost, name
+    # a non-finite SOURCE point: the reference's sums go NaN from the first iteration; seeded and unseeded agree on that too
+    # (compared through the neighbours of the first two steps)
+    for env in ("1", "0"):
+        knob.set("ICPX_GRID_SEED", env)
+        cfg = icp.Config()
+        cfg.set("nn", "grid")
+        x = icp.ICP3.from_method("vanilla", cfg)
+        x.begin(bad_q, bad_t, np.eye(4))
+        x.iterate()
+        x.iterate()
+        nb = [np.array(u) for u in x.debug_neighbors()]
+        if env == "1":
+            first = nb
+        else:
+            for u, v in zip(first, nb):
+                assert np.array_equal(u, v, equal_nan=True)
+    knob.reset("ICPX_GRID_SEED")
