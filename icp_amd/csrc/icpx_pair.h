@@ -518,6 +518,9 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
     //      every other target of the cloud.  Exact distances to the targets of the 2^D cells nearest to it, and
     //      the distance to the faces of that block behind which there are cells (everything outside the block
     //      is at least that far) ----
+    double inv_scale[D];  // (a rounding away from 1 / scale: covered by the 1e-6 below)
+#pragma unroll
+    for (int d = 0; d < D; d++) inv_scale[d] = scale[d] > 0.0 ? 1.0 / scale[d] : 0.0;
     for (int j = tid; j < cnt; j += T) {
         double t[D], h2 = __builtin_inf(), face = __builtin_inf();
         int b0[D], b1[D];
@@ -534,25 +537,48 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
             // with 1e-9 cells (+ 1e-9 relative) against the roundings of u
             const double slack = 1e-9 * (__builtin_fabs(x) + 1.0);
             if (scale[d] > 0.0) {
-                if (b1[d] < G - 1) face = __builtin_fmin(face, __builtin_fmax(static_cast<double>(b1[d] + 1) - x - slack, 0.0) / scale[d]);
-                if (b0[d] > 0) face = __builtin_fmin(face, __builtin_fmax(x - static_cast<double>(b0[d]) - slack, 0.0) / scale[d]);
+                if (b1[d] < G - 1) face = __builtin_fmin(face, __builtin_fmax(static_cast<double>(b1[d] + 1) - x - slack, 0.0) * inv_scale[d]);
+                if (b0[d] > 0) face = __builtin_fmin(face, __builtin_fmax(x - static_cast<double>(b0[d]) - slack, 0.0) * inv_scale[d]);
             }
         }
-        for (int cz = (D == 3 ? b0[D - 1] : 0); cz <= (D == 3 ? b1[D - 1] : 0); cz++)
-            for (int cy = b0[1]; cy <= b1[1]; cy++) {
-                const int row = (cz * G + cy) * G;
-                const int s = cursor[row + b0[0]] - hist[row + b0[0]], e = cursor[row + b1[0]];
-                for (int jj = s; jj < e; jj++) {
-                    if (jj == j) continue;
-                    double acc = 0.0;
+        // the block's (up to 2 x 2) rows as ONE sequence of slots: all row bounds first, then two slots per step
+        // (row by row, every row is a chain of LDS round trips that the whole wave waits for)
+        constexpr int NRC = D == 3 ? 4 : 2;
+        int pre[NRC], off[NRC], total = 0;
 #pragma unroll
-                    for (int d = 0; d < D; d++) {
-                        const double df = ts[d * ts_stride + jj] - t[d];
-                        acc = acc + df * df;
-                    }
-                    h2 = __builtin_fmin(h2, acc);
+        for (int r = 0; r < NRC; r++) {
+            const int cy = b0[1] + (r & 1), cz = D == 3 ? b0[D - 1] + (r >> 1) : 0;
+            const bool in = cy <= b1[1] && (D == 2 || cz <= b1[D - 1]);
+            const int row = in ? (cz * G + cy) * G : 0;
+            const int s = cursor[row + b0[0]] - hist[row + b0[0]], e = cursor[row + b1[0]];
+            pre[r] = total;
+            off[r] = s - total;
+            total += in ? e - s : 0;
+        }
+        for (int r0 = 0; r0 < total; r0 += 2) {
+            int jj[2];
+            double acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int r = r0 + u < total ? r0 + u : total - 1;
+                int o = off[0];
+#pragma unroll
+                for (int q = 1; q < NRC; q++) o = r >= pre[q] ? off[q] : o;
+                jj[u] = r + o;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                acc[u] = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const double df = ts[d * ts_stride + jj[u]] - t[d];
+                    acc[u] = acc[u] + df * df;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (jj[u] != j) h2 = __builtin_fmin(h2, acc[u]);
+        }
         double h = __builtin_fmin(__builtin_sqrt(h2), face) * (1.0 - 1e-6);  // below the true value, f32 rounding included
         if (!(h > 1e-30) || any_bad) h = 0.0;                                 // duplicates, tiny or unusable: never certify
         hc[j] = h < 1e30 ? static_cast<float>(h) : 1e30f;

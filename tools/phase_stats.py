@@ -14,7 +14,7 @@ icp_amd.converge_batch(dim, method, s, off, t, off, crit, device=0)
 lib.icpx_debug_stats(out, 1)
 icp_amd.converge_batch(dim, method, s, off, t, off, crit, device=0)
 lib.icpx_debug_stats(out, 0)
-tot = pairs * iters
+tot = pairs * max(iters, 1)
 for nm, i in (("search", 8), ("selection", 9), ("sums", 10), ("kabsch+broadcast", 11)):
     print(f"{nm:18s} {out[i] / tot / 100:8.2f} us per pair-iteration")
 print("raw counters:", [int(out[i]) for i in range(32)])
