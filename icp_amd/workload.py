@@ -37,7 +37,8 @@ class Config5Shard:
         self.crit = api.make_criteria(max_iterations=MAX_ITER, transform_tol=TOL)
         self.st2 = torch.cuda.Stream(self.dev)
         self.st3 = torch.cuda.Stream(self.dev)
-        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self.ev = None          # the four events of the last timed step
+        self.timed = []         # ... of every timed step since the last launch_ms_all()
         self.ev_begin = torch.cuda.Event()
 
     def step(self, timed: bool = False):
@@ -49,6 +50,9 @@ class Config5Shard:
         # compute unit each, start on the units the 2D pairs leave and take their tasks from the 3D launch's queue.
         # The 3D launch runs on a second stream that waits for what was on the caller's stream BEFORE this step (not
         # for the 2D launch), and the caller's stream joins it at the end: one cross-stream hand-over per step.
+        if timed:  # events of this step's own (read after the timed region: no host synchronisation between steps)
+            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            self.timed.append(self.ev)
         self.ev_begin.record(cur)
         if self.p3:
             self.st3.wait_event(self.ev_begin)
@@ -73,6 +77,14 @@ class Config5Shard:
         self.torch.cuda.synchronize(self.dev)
         k3 = self.ev[0].elapsed_time(self.ev[1]) if self.p3 else 0.0
         k2 = self.ev[2].elapsed_time(self.ev[3]) if self.p2 else 0.0
+        return k3, k2
+
+    def launch_ms_all(self):
+        """([3D launch ms], [2D launch ms]) of every timed step since the last call; synchronises once."""
+        self.torch.cuda.synchronize(self.dev)
+        k3 = [e[0].elapsed_time(e[1]) for e in self.timed] if self.p3 else []
+        k2 = [e[2].elapsed_time(e[3]) for e in self.timed] if self.p2 else []
+        self.timed = []
         return k3, k2
 
     def launch_alone_ms(self, dim: int, reps: int = 5) -> float:
