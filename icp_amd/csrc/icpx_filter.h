@@ -94,11 +94,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   0 seeded scans (wave)  1 exact flushes (wave)  2 two-min scans (wave)  3 near-tie lanes  4 slot rescans (wave)
 #ifdef ICPX_STATS
 __device__ unsigned long long g_icpx_stats[32];
+#ifdef ICPX_CYCONLY
+#define ICPX_STAT(slot_, amount_) do { } while (0)
+#else
 #define ICPX_STAT(slot_, amount_)                                                                    \
     do {                                                                                             \
         unsigned long long stat_v_ = (unsigned long long)(amount_);                                  \
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_icpx_stats[slot_], stat_v_);                       \
     } while (0)
+#endif
 // cycle stamps of wave 0 (s_memtime): ICPX_CYC_BEGIN(); ... ICPX_CYC(slot); ... ICPX_CYC(slot2);
 #define ICPX_CYC_BEGIN() unsigned long long cyc_t0_ = __builtin_amdgcn_s_memtime()
 #define ICPX_CYC(slot_)                                                                              \

@@ -388,6 +388,12 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     ICPX_CYC(19);  // list
+#ifdef ICPX_CYCONLY
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_icpx_stats[6], 1ull);
+        atomicAdd(&g_icpx_stats[7], static_cast<unsigned long long>(base));
+    }
+#endif
     if (threadIdx.x == 0) ICPX_STAT(22, base);
     ICPX_STAT(26, base);
     ICPX_STAT(27, 64 * kCoopBlock * ((base + 64 * kCoopBlock - 1) / (64 * kCoopBlock)));
@@ -663,6 +669,9 @@ ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded
         return;
     }
     const int G = P.g.G;
+#ifdef ICPX_CYCONLY
+    unsigned long long slot_t0_ = __builtin_amdgcn_s_memtime();
+#endif
     int r0[D], r1[D];  // box of the current bound
     int stage = 0;
     if (seeded) {
@@ -739,7 +748,16 @@ ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded
         } else if (walk) {
             stage = 3;
         }
+#ifdef ICPX_CYCONLY
+        if (threadIdx.x == 0) atomicAdd(&g_icpx_stats[5], 1ull);  // trips
+#endif
     }
+#ifdef ICPX_CYCONLY
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_icpx_stats[3], __builtin_amdgcn_s_memtime() - slot_t0_);
+        atomicAdd(&g_icpx_stats[4], 1ull);
+    }
+#endif
 }
 
 }  // namespace icpx
