@@ -31,7 +31,9 @@ struct GridIndex;
 int grid_create(GridIndex** out);
 void grid_destroy(GridIndex* g);
 // d_t: DEVICE pointer, AoS dim x m.  Synchronises the stream once (bounding box read-back).
-int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream);
+// defer: the first round's occupied-cell count is not waited for; call grid_settle before using occupancy or querying
+int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream, bool defer = false);
+int grid_settle(GridIndex* g, hipStream_t stream, bool* rebuilt);
 // d_q / d_idx / d_d2: DEVICE pointers (idx, d2 may be null).  visited (device u64, may be null)
 // accumulates the number of candidate targets examined.
 int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,

@@ -52,6 +52,18 @@ struct GridIndex {
     double occupied_frac = 0.0;  // share of the cells that hold a target (grid_build)
     double per_occupied = 0.0;   // targets per occupied cell after the refinement (grid_build)
     int64_t q_perm_n = 0;
+    // grid_build(defer = true): the occupied-cell count of the first round is read back by grid_settle, after the
+    // caller has enqueued the work that follows the build — the build's second host round trip leaves the critical path
+    struct Build {
+        const double* d_t = nullptr;
+        int64_t m = 0, max_cells = 0;
+        double ext[3] = {0, 0, 0}, h = 1.0;
+        int nz = 0;
+    } b;
+    bool refined_last = false;    // the last build needed a finer round: the next one does not defer (it would build twice)
+    int* occ_host = nullptr;      // pinned
+    hipEvent_t occ_ev = nullptr;
+    bool occ_pending = false;
 };
 
 struct BvhIndex {
@@ -936,6 +948,8 @@ void grid_destroy(GridIndex* g) {
     for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys, &g->totals, &g->q_keys, &g->q_keys_out,
                       &g->q_iota, &g->q_perm, &g->q_tmp, &g->q_start})
         b->release();
+    if (g->occ_host) (void)hipHostFree(g->occ_host);
+    if (g->occ_ev) (void)hipEventDestroy(g->occ_ev);
     delete g;
 }
 
@@ -944,8 +958,13 @@ void grid_destroy(GridIndex* g) {
 constexpr double kGridDegenerate = 48.0;
 bool grid_degenerate(const GridIndex* g) { return g->per_occupied > kGridDegenerate; }
 
-int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream) {
+int grid_count_rounds(GridIndex* g, hipStream_t stream, int first, bool defer);
+int grid_scan_scatter(GridIndex* g, hipStream_t stream);
+bool grid_wants_finer(GridIndex* g, int occ);
+
+int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream, bool defer) {
     g->dim = dim;
+    g->occ_pending = false;
     GridParams& gp = g->gp;
     std::memset(&gp, 0, sizeof(gp));
     gp.m = m;
@@ -975,50 +994,70 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
     ICPX_HIP(hipMemcpyAsync(keys, g->keys.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
     ICPX_HIP(hipStreamSynchronize(stream));
     // 2. cell size: about 2 targets per cell over the non-degenerate axes
-    double ext[3] = {0, 0, 0};
-    int nz = 0;
+    GridIndex::Build& bs = g->b;
+    bs.d_t = d_t;
+    bs.m = m;
+    bs.nz = 0;
     double vol = 1.0;
     bool any = keys[0] != ~0ULL;
+    for (int d = 0; d < 3; d++) bs.ext[d] = 0.0;
     for (int d = 0; d < dim; d++) {
         gp.lo[d] = any ? f64_unkey(keys[d]) : 0.0;
         gp.hi[d] = any ? f64_unkey(keys[3 + d]) : 0.0;
-        ext[d] = gp.hi[d] - gp.lo[d];
-        if (ext[d] > 0.0 && std::isfinite(ext[d])) {
-            nz++;
-            vol *= ext[d];
+        bs.ext[d] = gp.hi[d] - gp.lo[d];
+        if (bs.ext[d] > 0.0 && std::isfinite(bs.ext[d])) {
+            bs.nz++;
+            vol *= bs.ext[d];
         } else {
-            ext[d] = 0.0;
+            bs.ext[d] = 0.0;
         }
     }
     const double target_cells = std::max<double>(1.0, static_cast<double>(m) / 2.0);
-    double h = 1.0;
-    if (nz > 0) {
-        h = std::pow(vol / target_cells, 1.0 / nz);
-        if (!(h > 0.0) || !std::isfinite(h)) h = 1.0;
+    bs.h = 1.0;
+    if (bs.nz > 0) {
+        bs.h = std::pow(vol / target_cells, 1.0 / bs.nz);
+        if (!(bs.h > 0.0) || !std::isfinite(bs.h)) bs.h = 1.0;
     }
-    const int64_t max_cells = std::min<int64_t>(16 * m + 64, int64_t(1) << 26);
+    bs.max_cells = std::min<int64_t>(16 * m + 64, int64_t(1) << 26);
     ICPX_TRY(g->cell_id.reserve(sizeof(int) * m));
     ICPX_TRY(g->recs.reserve(sizeof(GridRec) * m));
+    g->occ_pending = false;
+    if (defer) {
+        if (!g->occ_host) ICPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->occ_host), sizeof(int), hipHostMallocDefault));
+        if (!g->occ_ev) ICPX_HIP(hipEventCreateWithFlags(&g->occ_ev, hipEventDisableTiming));
+    }
+    defer = defer && !g->refined_last;  // clouds that needed a finer round last time are counted the patient way
+    g->refined_last = false;
+    ICPX_TRY(grid_count_rounds(g, stream, 0, defer));
+    return grid_scan_scatter(g, stream);
+}
+
+// 3. count per cell; surfaces and clusters leave most cells empty, so the edge is halved while the OCCUPIED cells
+//    hold more than ~6 targets on average and the cell budget allows.  Rounds first .. 4; with `defer` round 0 does
+//    not wait for its occupied-cell count (grid_settle does).
+int grid_count_rounds(GridIndex* g, hipStream_t stream, int first, bool defer) {
+    GridIndex::Build& bs = g->b;
+    GridParams& gp = g->gp;
+    const int dim = g->dim;
+    const int64_t m = bs.m;
     const unsigned mb = static_cast<unsigned>((m + 255) / 256);
-    int64_t total = 1;
-    // 3. count per cell; surfaces and clusters leave most cells empty, so the edge is halved while
-    //    the OCCUPIED cells hold more than ~6 targets on average and the cell budget allows
-    for (int refine = 0; refine < 5; refine++) {
+    for (int refine = first; refine < 5; refine++) {
+        int64_t total = 1;
         for (int attempt = 0; attempt < 64; attempt++) {
             total = 1;
             for (int d = 0; d < dim; d++) {
-                double cnt = ext[d] > 0.0 ? std::floor(ext[d] / h) + 1.0 : 1.0;
+                double cnt = bs.ext[d] > 0.0 ? std::floor(bs.ext[d] / bs.h) + 1.0 : 1.0;
                 if (cnt > 2.0e6) cnt = 2.0e6;
                 gp.g[d] = static_cast<int>(cnt);
                 total *= gp.g[d];
             }
-            if (total <= max_cells) break;
-            h *= 1.26;  // ~ 2^(1/3): halve the cell count per retry in 3D
+            if (total <= bs.max_cells) break;
+            bs.h *= 1.26;  // ~ 2^(1/3): halve the cell count per retry in 3D
         }
-        if (total > max_cells) return fail(ICPX_ERR_UNSUPPORTED, "grid: degenerate cloud extents");
+        if (total > bs.max_cells) return fail(ICPX_ERR_UNSUPPORTED, "grid: degenerate cloud extents");
         for (int d = 0; d < dim; d++) {
-            gp.h[d] = h;
-            gp.inv_h[d] = 1.0 / h;
+            gp.h[d] = bs.h;
+            gp.inv_h[d] = 1.0 / bs.h;
         }
         gp.rmax = std::max(gp.g[0], std::max(gp.g[1], gp.g[2])) - 1;
         g->ncell = static_cast<int>(total);
@@ -1026,29 +1065,48 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
         ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 2), stream));
         int* d_occ = g->counts.as<int>() + total + 1;
         if (dim == 2)
-            hipLaunchKernelGGL(grid_count_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
+            hipLaunchKernelGGL(grid_count_kernel<2>, dim3(mb), dim3(256), 0, stream, bs.d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
         else
-            hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
+            hipLaunchKernelGGL(grid_count_kernel<3>, dim3(mb), dim3(256), 0, stream, bs.d_t, gp, g->cell_id.as<int>(), g->counts.as<int>());
         ICPX_HIP(hipGetLastError());
         g->occupied_frac = 0.0;
         g->per_occupied = static_cast<double>(m);  // (all targets in one point: one cell)
-        if (nz == 0) break;
+        if (bs.nz == 0) break;
         hipLaunchKernelGGL(grid_occupied_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 1024))), dim3(256), 0,
                            stream, g->counts.as<int>(), static_cast<int>(total), d_occ);
         ICPX_HIP(hipGetLastError());
+        if (defer && refine == 0) {
+            ICPX_HIP(hipMemcpyAsync(g->occ_host, d_occ, sizeof(int), hipMemcpyDeviceToHost, stream));
+            ICPX_HIP(hipEventRecord(g->occ_ev, stream));
+            g->occ_pending = true;
+            return ICPX_OK;
+        }
         int occ = 0;
         ICPX_HIP(hipMemcpyAsync(&occ, d_occ, sizeof(int), hipMemcpyDeviceToHost, stream));
         ICPX_HIP(hipStreamSynchronize(stream));
-        g->occupied_frac = static_cast<double>(occ) / static_cast<double>(total);
-        g->per_occupied = occ > 0 ? static_cast<double>(m) / occ : 0.0;
-        if (occ <= 0 || static_cast<double>(m) / occ <= 6.0) break;
-        // would the halved grid still fit?
-        double next_total = 1.0;
-        for (int d = 0; d < dim; d++) next_total *= ext[d] > 0.0 ? std::floor(ext[d] / (0.5 * h)) + 1.0 : 1.0;
-        if (next_total > static_cast<double>(max_cells)) break;
-        h *= 0.5;
+        if (!grid_wants_finer(g, occ)) break;
+        bs.h *= 0.5;
+        g->refined_last = true;
     }
-    // 4. exclusive scan -> cell starts, then scatter into cell order
+    return ICPX_OK;
+}
+
+// occupancy of the round just counted; true: the grid fits and should be counted again with half the edge
+bool grid_wants_finer(GridIndex* g, int occ) {
+    const GridIndex::Build& bs = g->b;
+    const int64_t total = g->ncell;
+    g->occupied_frac = static_cast<double>(occ) / static_cast<double>(total);
+    g->per_occupied = occ > 0 ? static_cast<double>(bs.m) / occ : 0.0;
+    if (occ <= 0 || static_cast<double>(bs.m) / occ <= 6.0) return false;
+    double next_total = 1.0;
+    for (int d = 0; d < g->dim; d++) next_total *= bs.ext[d] > 0.0 ? std::floor(bs.ext[d] / (0.5 * bs.h)) + 1.0 : 1.0;
+    return next_total <= static_cast<double>(bs.max_cells);
+}
+
+// 4. exclusive scan -> cell starts, then scatter into cell order
+int grid_scan_scatter(GridIndex* g, hipStream_t stream) {
+    const int64_t total = g->ncell, m = g->b.m;
+    const unsigned mb = static_cast<unsigned>((m + 255) / 256);
     ICPX_TRY(g->start.reserve(sizeof(int) * (total + 1)));
     const int nb = static_cast<int>((total + kScanBlk - 1) / kScanBlk);
     ICPX_TRY(g->totals.reserve(sizeof(int) * (nb + 1)));
@@ -1059,14 +1117,30 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
     hipLaunchKernelGGL(grid_scan_local_kernel, dim3(nb), dim3(256), 0, stream, g->counts.as<int>(), g->ncell, g->totals.as<int>(), g->start.as<int>());
     ICPX_HIP(hipGetLastError());
     ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 2), stream));  // reuse as cursors
-    if (dim == 2)
-        hipLaunchKernelGGL(grid_scatter_kernel<2>, dim3(mb), dim3(256), 0, stream, d_t, m, g->cell_id.as<int>(),
+    if (g->dim == 2)
+        hipLaunchKernelGGL(grid_scatter_kernel<2>, dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
                            g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>());
     else
-        hipLaunchKernelGGL(grid_scatter_kernel<3>, dim3(mb), dim3(256), 0, stream, d_t, m, g->cell_id.as<int>(),
+        hipLaunchKernelGGL(grid_scatter_kernel<3>, dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
                            g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>());
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
+}
+
+// After grid_build(defer = true) and whatever the caller enqueued behind it: reads the first round's occupied-cell
+// count.  *rebuilt = the grid was counted again with a finer cell and rebuilt (the work enqueued behind the first
+// build used the coarser grid: the caller repeats it).
+int grid_settle(GridIndex* g, hipStream_t stream, bool* rebuilt) {
+    *rebuilt = false;
+    if (!g->occ_pending) return ICPX_OK;
+    g->occ_pending = false;
+    ICPX_HIP(hipEventSynchronize(g->occ_ev));
+    if (!grid_wants_finer(g, *g->occ_host)) return ICPX_OK;
+    g->b.h *= 0.5;
+    g->refined_last = true;
+    ICPX_TRY(grid_count_rounds(g, stream, 1, false));
+    *rebuilt = true;
+    return grid_scan_scatter(g, stream);
 }
 
 // rocPRIM sorts up to 2^20 items by block sort + ~log2(n / 1024) merge passes; for keys of few bits the one-sweep
@@ -1182,10 +1256,14 @@ int grid_profile(GridIndex* g, int dim, const double* d_q, int64_t n, const doub
 
 int grid_nn_oneshot(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
                     double* d_d2, hipStream_t stream, BvhIndex* degenerate_to) {
-    int rc = grid_build(g, dim, d_t, m, stream);
+    // the occupied-cell count of the build is read after the query order has been enqueued (grid_settle)
+    int rc = grid_build(g, dim, d_t, m, stream, true);
+    if (rc == ICPX_OK) rc = grid_sort_queries(g, d_q, n, stream);
+    bool rebuilt = false;
+    if (rc == ICPX_OK) rc = grid_settle(g, stream, &rebuilt);
     if (rc == ICPX_OK && degenerate_to != nullptr && grid_degenerate(g))
         return bvh_nn_oneshot(degenerate_to, dim, d_q, n, d_t, m, d_idx, d_d2, stream);  // (declared in icpx_large.h)
-    if (rc == ICPX_OK) rc = grid_sort_queries(g, d_q, n, stream);
+    if (rc == ICPX_OK && rebuilt) rc = grid_sort_queries(g, d_q, n, stream);  // (the order was that of the coarser grid)
     if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, d_idx, d_d2, nullptr, stream);
     if (rc == ICPX_OK) {
         hipError_t e = hipStreamSynchronize(stream);
