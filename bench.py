@@ -82,11 +82,12 @@ def main():
     sh = workload.Config5Shard(torch, rank, world, total2, total3, local_rank)
     s2, t2, off2, s3, t3, off3 = sh.s2, sh.t2, sh.off2, sh.s3, sh.t3, sh.off3
     k3_ms, k2_ms = [], []
+    gather_scratch = {}
 
     def step(timed_kernel=False):
         sh.step(timed=timed_kernel)
         if world > 1:
-            gathered = shard.gather_states(sh.out, total2 + total3, rank, world, counts=(total2, total3))
+            gathered = shard.gather_states(sh.out, total2 + total3, rank, world, counts=(total2, total3), scratch=gather_scratch)
         # (the launches' HIP events are read after the timed region: nothing synchronises the host between steps)
 
     def barrier():

@@ -158,6 +158,24 @@ if rank == 0:
         r = ob.OracleICP(2, 'trimmed').converge(src[off[k]:off[k+1]], dst[off[k]:off[k+1]], None, crit)
         assert allst[k, 1] == r.iteration_count and allst[k, 0] == r.cost, k
         assert np.array_equal(allst[k, 2:11].numpy(), r.transform.flatten(order='F'))
+# ragged shards and several independently sharded groups, as bench.py gathers them (2D pairs, then 3D pairs):
+# row r of a rank's block carries (group, global pair id)
+for groups in ((7,), (5, 4), (3, 3), (1, 6), (4, 2), (8,)):
+    mine = []
+    for gi, g in enumerate(groups):
+        lo, hi = shard.shard_range(g, rank, world)
+        mine += [[gi, p] + [0.0] * 16 for p in range(lo, hi)]
+    local = torch.tensor(mine, dtype=torch.float64).reshape(-1, 18)
+    scratch = {{}}
+    for rep in range(2):   # (the second call reuses the scratch buffer)
+        tab = shard.gather_states(local, sum(groups), rank, world, counts=groups, scratch=scratch)
+        want = []
+        for r in range(world):
+            for gi, g in enumerate(groups):
+                lo, hi = shard.shard_range(g, r, world)
+                want += [[gi, p] for p in range(lo, hi)]
+        assert tab.shape[0] == sum(groups) and tab[:, :2].tolist() == [[float(a), float(b)] for a, b in want], (groups, tab[:, :2])
+if rank == 0:
     print('OK')
 dist.destroy_process_group()
 """)
