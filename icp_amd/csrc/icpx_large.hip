@@ -534,6 +534,39 @@ ICPX_DEV void group_tree(F&& f, int64_t n, double* __restrict__ part, int G1) {
 }
 
 // remaining TREE64 levels over the per-block (or per-group) partials; every thread gets the total.
+// NV values at once (value v's partials at part + v * nblk): the (value, group of 64 partials) pairs are spread over the
+// block's waves and every wave finishes all NV second levels — the same additions as NV calls of fin_tree, with one
+// pair of barriers and the loads of all values in flight together instead of a round trip per value.
+// lds: NV * 64 doubles.
+template <int NV>
+ICPX_DEV void fin_tree_many(const double* __restrict__ part, int nblk, double* lds, double (&out)[NV]) {
+    if (nblk == 1) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) out[v] = part[v];
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int G = (nblk + 63) >> 6;
+    for (int t = wave; t < NV * G; t += W) {
+        const int v = t / G, g = t - v * G;
+        const int j = g * 64 + lane;
+        const double x = j < nblk ? part[static_cast<int64_t>(v) * nblk + j] : 0.0;
+        const double sum = wave_sum(x);
+        if (lane == 0) lds[v * 64 + g] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        if (G == 1) {
+            out[v] = lds[v * 64];
+        } else {
+            const double x = lane < G ? lds[v * 64 + lane] : 0.0;
+            out[v] = wave_sum(x);
+        }
+    }
+    __syncthreads();
+}
+
 ICPX_DEV double fin_tree(const double* __restrict__ part, int nblk, double* lds) {
     if (nblk == 1) return part[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
@@ -793,11 +826,11 @@ template <int D>
 __global__ void __launch_bounds__(kBlk)
 lg_fin1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, const int* __restrict__ cntp,
                int nblk) {
-    __shared__ double lds[64];
+    __shared__ double lds[(2 * D + 1) * 64];
     __shared__ int wcnt[kBlk / 64];
     if (respect_done && dev->st.done) return;
     double s[2 * D + 1];
-    for (int v = 0; v < 2 * D + 1; v++) s[v] = fin_tree(part + static_cast<int64_t>(v) * nblk, nblk, lds);
+    fin_tree_many<2 * D + 1>(part, nblk, lds, s);
     int c = 0;  // <= 2^24 selected points in all
     for (int b = threadIdx.x; b < nblk; b += blockDim.x) c += cntp[b];
     c = wave_sum_int(c);
@@ -881,11 +914,11 @@ template <int D, int METHOD>
 __global__ void __launch_bounds__(kBlk)
 lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, int nblk, double n_points,
                int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s) {
-    __shared__ double lds[64];
+    __shared__ double lds[D * D * 64];
     constexpr int XN = (D + 1) * (D + 1);
     if (respect_done && dev->st.done) return;
     double s[D * D];
-    for (int v = 0; v < D * D; v++) s[v] = fin_tree(part + static_cast<int64_t>(v) * nblk, nblk, lds);
+    fin_tree_many<D * D>(part, nblk, lds, s);
     if (threadIdx.x == 0) {
         Mat<D> N;
 #pragma unroll
