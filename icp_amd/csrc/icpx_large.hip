@@ -110,6 +110,7 @@ struct LargeIcp {
     GridIndex* grid = nullptr;
     BvhIndex* bvh = nullptr;   // built instead of / after the grid: nn = bvh, or nn = auto with a degenerate grid
     bool use_bvh = false;
+    int tile_qpt = 4;        // queries per thread of the tiled search (large_begin)
     bool nn_seeded = false;  // nb_idx holds the neighbours of an earlier correspondence step of this begin()
     DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
     // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
@@ -290,11 +291,13 @@ constexpr int64_t kGridSortMinQueries = 32768;
 #define ICPX_TILE_THREADS 256
 #endif
 constexpr int kTileThreads = ICPX_TILE_THREADS;
-#ifndef ICPX_TILE_QPT
-#define ICPX_TILE_QPT 4
+#ifdef ICPX_TILE_QPT
+constexpr int kTileQpt = ICPX_TILE_QPT;   // development: fixed queries per thread (1, 2 or 4)
+constexpr bool kTileQptAuto = false;
+#else
+constexpr int kTileQpt = 4;
+constexpr bool kTileQptAuto = true;
 #endif
-constexpr int kTileQpt = ICPX_TILE_QPT;
-constexpr int kTileQueries = kTileThreads * kTileQpt;
 constexpr int kTileScratch = 96;  // doubles of reduction scratch
 constexpr int kTileMaxSplit = 3072;  // targets per split at most (3D: 110 KB of LDS)
 constexpr int kTileMinSplit = 512;
@@ -340,7 +343,7 @@ __global__ void lg_step_kernel(LargeDev* dev, int respect_done, double* __restri
 
 // MODE as in lg_nn_kernel (0: queries = running cloud, already stepped; 1: untransformed source;
 // 2: transform * source)
-template <int D, int MODE>
+template <int D, int MODE, int QPT>
 __global__ void __launch_bounds__(kTileThreads)
 lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                   int64_t n, const double* __restrict__ dst, int64_t m, int split_len, int scap,
@@ -366,10 +369,10 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
     L.j0 = static_cast<int>(t0);
     // queries and seed indices first: their loads are in flight while the split is staged
-    double q[kTileQpt][D], best[kTileQpt];
-    int bidx[kTileQpt];
-    int64_t seed[kTileQpt];
-    const int64_t qbase = static_cast<int64_t>(blockIdx.x) * kTileQueries;
+    double q[QPT][D], best[QPT];
+    int bidx[QPT];
+    int64_t seed[QPT];
+    const int64_t qbase = static_cast<int64_t>(blockIdx.x) * (kTileThreads * QPT);
     const bool seeded = dev->nn_valid != 0;
     XfRows<D> xr;
     if (MODE == 2 || MODE == 3) {
@@ -379,7 +382,7 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
         xr = xf_rows<D>(X);
     }
 #pragma unroll
-    for (int k = 0; k < kTileQpt; k++) {
+    for (int k = 0; k < QPT; k++) {
         const int64_t i = qbase + tid + k * kTileThreads;
         const bool valid = i < n;
         double pnt[D];
@@ -396,7 +399,7 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     }
     const FilterFrame F = stage_targets<D>(dst + t0 * D, mt, m4, kTileThreads, L, true);
 #pragma unroll
-    for (int k = 0; k < kTileQpt; k++) {
+    for (int k = 0; k < QPT; k++) {
         best[k] = __builtin_inf();
         bidx[k] = 0x7fffffff;
         if (seeded) {
@@ -413,10 +416,10 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
             bidx[k] = static_cast<int>(j);
         }
     }
-    if (seeded) nn_filtered<D, kTileQpt>(q, L, m4, F, best, bidx);
-    else nn_twomin<D, kTileQpt>(q, L, m4, F, best, bidx);
+    if (seeded) nn_filtered<D, QPT>(q, L, m4, F, best, bidx);
+    else nn_twomin<D, QPT>(q, L, m4, F, best, bidx);
 #pragma unroll
-    for (int k = 0; k < kTileQpt; k++) {
+    for (int k = 0; k < QPT; k++) {
         const int64_t i = qbase + tid + k * kTileThreads;
         if (i < n) {
             part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = best[k];
@@ -1608,7 +1611,8 @@ int enqueue_nn(LargeIcp* lg, int respect) {
         hipLaunchKernelGGL(lg_step_kernel<D>, dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->cur.as<double>(), lg->n);
         ICPX_HIP(hipGetLastError());
     }
-    auto kern = lg_tile_nn_kernel<D, MODE>;
+    // queries per thread (large_begin): 4, or fewer for clouds whose tiles would not fill the chip
+    auto kern = lg->tile_qpt == 1 ? lg_tile_nn_kernel<D, MODE, 1> : (lg->tile_qpt == 2 ? lg_tile_nn_kernel<D, MODE, 2> : lg_tile_nn_kernel<D, MODE, 4>);
     const size_t lds = tile_lds_bytes(D, lg->split_len);
     static std::mutex mu;
     static std::unordered_map<int, bool> attr_set;
@@ -1616,13 +1620,14 @@ int enqueue_nn(LargeIcp* lg, int respect) {
         int devid = 0;
         ICPX_HIP(hipGetDevice(&devid));
         std::lock_guard<std::mutex> lk(mu);
-        if (!attr_set[devid]) {
+        if (!attr_set[devid * 8 + lg->tile_qpt]) {
             ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          static_cast<int>(tile_lds_bytes(3, kTileMaxSplit))));
-            attr_set[devid] = true;
+            attr_set[devid * 8 + lg->tile_qpt] = true;
         }
     }
-    dim3 grid(static_cast<unsigned>((lg->n + kTileQueries - 1) / kTileQueries), static_cast<unsigned>(lg->splits));
+    const int64_t tile_queries = static_cast<int64_t>(kTileThreads) * lg->tile_qpt;
+    dim3 grid(static_cast<unsigned>((lg->n + tile_queries - 1) / tile_queries), static_cast<unsigned>(lg->splits));
     hipLaunchKernelGGL(kern, grid, dim3(kTileThreads), lds, lg->stream, dev, respect, lg->src.as<double>(),
                        lg->cur.as<double>(), lg->n, lg->dst.as<double>(), lg->m, lg->split_len, lg->split_len,
                        lg->nb_idx.as<int64_t>(), lg->part_d2.as<double>(), lg->part_idx.as<int32_t>());
@@ -1764,9 +1769,19 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
                (lg->prm.nn_mode != ICPX_NN_GRID && lg->prm.nn_mode != ICPX_NN_BVH &&
                 static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
     if (lg->tile) {
-        const int64_t ntq = (n + kTileQueries - 1) / kTileQueries;
-        int64_t splits = (768 + ntq - 1) / ntq;                       // aim at ~3 workgroups per CU
         const int64_t most = (m + kTileMinSplit - 1) / kTileMinSplit;  // splits of at least kTileMinSplit targets
+        // queries per thread: four, unless the cloud then gives fewer than ~3 workgroups per CU even with the most
+        // splits — one wave per SIMD leaves every load of the search exposed (queen, 10 720 points: 231 workgroups,
+        // 1.43 ms; 882 workgroups with one query per thread, 1.21 ms); ICPX_TILE_QPT fixes it (development)
+        lg->tile_qpt = kTileQpt;
+        if (kTileQptAuto)
+            for (int qpt = 4; qpt >= 1; qpt >>= 1) {
+                lg->tile_qpt = qpt;
+                if (((n + kTileThreads * qpt - 1) / (kTileThreads * qpt)) * most >= 768) break;
+            }
+        const int64_t tile_queries = static_cast<int64_t>(kTileThreads) * lg->tile_qpt;
+        const int64_t ntq = (n + tile_queries - 1) / tile_queries;
+        int64_t splits = (768 + ntq - 1) / ntq;                       // aim at ~3 workgroups per CU
         if (splits > most) splits = most;
         if (splits < 1) splits = 1;
         int64_t len = ((m + splits - 1) / splits + 3) & ~int64_t(3);
