@@ -171,7 +171,9 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost
 // qstart != null: block-cooperative (icpx_grid.h) — one workgroup per block of tiles, its queries the range
 // [qstart[b], qstart[b + 1]) of the order `perm`; otherwise one query per thread.
 template <int D, int METHOD, int MODE>
-__global__ void __launch_bounds__(256)
+// (six waves per SIMD: the 80-register budget costs the per-lane walk nothing and hides more of its memory latency —
+// clustered config-4 converge 6.83 -> 6.55 ms; eight waves spill and lose)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
