@@ -996,3 +996,29 @@ def test_grid_seeded_query_is_bit_identical(icp, ob, knob):
             for u, v in zip(first, nb):
                 assert np.array_equal(u, v, equal_nan=True)
     knob.reset("ICPX_GRID_SEED")
+
+
+def test_tiled_search_queries_per_thread_variants(icp, ob):
+    """The tiled multi-kernel search picks one, two or four queries per thread from the cloud sizes (large_begin):
+    sizes that select two (14 000 x 14 000) and four (20 000 x 20 000) — the other large-path tests all select one —
+    against the oracle, transforms, cost and every neighbour; ragged sizes so that the last tile and split are partial."""
+    from icp_amd import synth
+    crit = dict(max_iterations=3, transform_tol=(1e-9, 1e-9))
+    for n, m in ((14_003, 13_999), (20_001, 20_010)):
+        s, t, _, _ = synth.config4(max(n, m))
+        s, t = s[:n], t[:m]
+        d = driver(icp, icp.ICP3, "vanilla", crit)
+        r = d.converge(s, t)
+        ro = dev_oracle(ob, 3, "vanilla").converge(s, t, None, ob.make_criteria(**crit))
+        assert r.iteration_count == ro.iteration_count, (n, m)
+        assert np.array_equal(r.transform, ro.transform) and r.cost == ro.cost, (n, m)
+    # neighbours after two explicit iterations at the four-queries size
+    x = icp.ICP3.from_method("vanilla")
+    o = dev_oracle(ob, 3, "vanilla")
+    x.begin(s, t, np.eye(4))
+    o.begin(s, t, np.eye(4))
+    for _ in range(2):
+        x.iterate()
+        o.iterate()
+    for u, v in zip(x.debug_neighbors(), o.neighbors()):
+        assert np.array_equal(u, v)
