@@ -1022,3 +1022,19 @@ def test_tiled_search_queries_per_thread_variants(icp, ob):
         o.iterate()
     for u, v in zip(x.debug_neighbors(), o.neighbors()):
         assert np.array_equal(u, v)
+
+
+def test_grid_build_deferred_occupancy_transitions(icp, queen):
+    """The stand-alone grid query reads the build's occupied-cell count after it has enqueued the query order
+    (grid_settle) and rebuilds when the cloud needs a finer cell; an index that was rebuilt counts the patient way next
+    time.  Clouds that do (queen.ply: a surface) and do not (uniform) need the finer round, alternating on one
+    workspace, each answer against the brute-force kernel."""
+    rng = np.random.default_rng(41)
+    uni_t = rng.uniform(-1, 1, (40_000, 3))
+    uni_q = rng.uniform(-1.1, 1.1, (40_000, 3))
+    qs, qt = queen
+    big_q = np.concatenate([qs] * 4) + rng.normal(0, 1e-3, (4 * len(qs), 3))   # >= 32 768 queries: ordered by tile
+    for q, t in ((uni_q, uni_t), (big_q, qt), (big_q, qt), (uni_q, uni_t), (uni_q, uni_t), (big_q, qt)):
+        ig, dg = icp.nearest_neighbors(q, t, icp.NN_GRID)
+        ib, db = icp.nearest_neighbors(q, t, icp.NN_BRUTE)
+        assert np.array_equal(ig, ib) and np.array_equal(dg, db)
