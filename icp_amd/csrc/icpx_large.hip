@@ -126,7 +126,9 @@ struct LargeIcp {
     // normalised feature-distance matrix, stored target-major ([j * n + i]) for coalesced reads
     bool feature = false;
     DevBuf f_rad, f_feat_a, f_feat_b, f_nfd;
-    int* h_done = nullptr;  // pinned
+    int* h_done = nullptr;  // pinned: [0] done flag, [1] iterations finished (written by the device, large_converge polls)
+    int* h_done_dev = nullptr;   // the same memory as the device sees it
+    int* poll_dev = nullptr;     // h_done_dev while large_converge runs, else null: kernels then publish nothing
     // host time at which lg_init_kernel (which samples the device's start_clock) was enqueued: the
     // time-limit test adds ONE host offset (converge's t0 -> this moment) to the device clock since then
     std::chrono::steady_clock::time_point init_at{};
@@ -896,10 +898,18 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
         block_tree<D * D>(terms, n, part, nblk, gs);
 }
 
+// done flag and iteration count into host memory (pinned, coherent) for large_converge, which polls them instead of
+// copying the flag and synchronising the stream after every chunk of iterations
+ICPX_DEV void publish_progress(int* hflags, int done, int iterations) {
+    if (!hflags) return;
+    if (done) __hip_atomic_store(&hflags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&hflags[1], iterations, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // setup tail: ICP::calculate_cost of the initial matches, then the loop's first should_terminate
 template <int D>
 __global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx_criteria crit,
-                                       double clock_to_s, double host_elapsed_s) {
+                                       double clock_to_s, double host_elapsed_s, int* hflags) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double sum = dev->with_cost ? dev->cost_sum : 0.0;
     dev->st.cost = __builtin_sqrt(sum / static_cast<double>(n));  // icp.h:149-155
@@ -913,12 +923,13 @@ __global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx
             dev->st.have_last = 1;
         }
     }
+    publish_progress(hflags, dev->st.done, static_cast<int>(dev->st.iteration_count));
 }
 
 template <int D, int METHOD>
 __global__ void __launch_bounds__(kBlk)
 lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, int nblk, double n_points,
-               int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s) {
+               int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s, int* hflags) {
     __shared__ double lds[D * D * 64];
     constexpr int XN = (D + 1) * (D + 1);
     if (respect_done && dev->st.done) return;
@@ -955,6 +966,7 @@ lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
                 dev->st.have_last = 1;
             }
         }
+        publish_progress(hflags, dev->st.done, static_cast<int>(dev->st.iteration_count));
     }
 }
 
@@ -1472,6 +1484,10 @@ int large_create(int dim, int method, const icpx_params& prm, double clock_to_s,
         delete lg;
         return fail(ICPX_ERR_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
     }
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&lg->h_done_dev), lg->h_done, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        lg->h_done_dev = nullptr;  // (large_converge then reads the flag with a copy, as before)
+    }
     *out = lg;
     return ICPX_OK;
 }
@@ -1663,7 +1679,7 @@ int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double hos
         ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
     }
     hipLaunchKernelGGL(lg_setup_finish_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, check, crit,
-                       lg->clock_to_s, host_elapsed_s);
+                       lg->clock_to_s, host_elapsed_s, lg->poll_dev);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1693,7 +1709,7 @@ int enqueue_iteration(LargeIcp* lg, int check, const icpx_criteria& crit, double
     ICPX_TRY((enqueue_sums<D, METHOD>(lg, respect, true)));
     hipLaunchKernelGGL((lg_fin2_kernel<D, METHOD>), dim3(1), dim3(kBlk), 0, lg->stream, dev, respect,
                        lg->part.as<double>(), lg->nblk, static_cast<double>(lg->n), check, crit, lg->clock_to_s,
-                       host_elapsed_s);
+                       host_elapsed_s, lg->poll_dev);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1844,17 +1860,50 @@ int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_
     LargeDev* dev = lg->dev.as<LargeDev>();
     // large_begin already ran setup without a check: evaluate the loop's first should_terminate
     if (lg->dim == 2)
+    // progress flags in pinned memory, written by the two kernels that can end the loop; the host polls them
+    // (a copy of the flag + a stream synchronisation per chunk left the GPU idle for ~25 us each time)
+    struct PollGuard {
+        LargeIcp* l;
+        ~PollGuard() { l->poll_dev = nullptr; }
+    } guard{lg};
+    lg->poll_dev = knobs().poll_done != 0 ? lg->h_done_dev : nullptr;
+    lg->h_done[0] = 0;
+    lg->h_done[1] = -1;
+    if (lg->dim == 2)
         hipLaunchKernelGGL(lg_setup_finish_kernel<2>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, 1, *crit,
-                           lg->clock_to_s, elapsed());
+                           lg->clock_to_s, elapsed(), lg->poll_dev);
     else
         hipLaunchKernelGGL(lg_setup_finish_kernel<3>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, 1, *crit,
-                           lg->clock_to_s, elapsed());
+                           lg->clock_to_s, elapsed(), lg->poll_dev);
     ICPX_HIP(hipGetLastError());
     uint64_t enq = 0;
     int chunk = 4;
     while (true) {
-        ICPX_HIP(hipMemcpyAsync(lg->h_done, &dev->st.done, sizeof(int), hipMemcpyDeviceToHost, lg->stream));
-        ICPX_HIP(hipStreamSynchronize(lg->stream));
+        // wait until the device reports `done` or all `enq` iterations enqueued so far
+        bool have = false;
+        if (lg->poll_dev) {
+            for (uint64_t spin = 1;; spin++) {
+                const int ticks = __atomic_load_n(&lg->h_done[1], __ATOMIC_ACQUIRE);
+                if (__atomic_load_n(&lg->h_done[0], __ATOMIC_ACQUIRE) != 0 || (ticks >= 0 && static_cast<uint64_t>(ticks) >= enq)) {
+                    have = true;
+                    break;
+                }
+                if ((spin & 0x3fff) == 0) {
+                    const hipError_t q = hipStreamQuery(lg->stream);
+                    if (q == hipSuccess) {
+                        // the stream has drained: its kernels' stores are visible now (or never came: read the flag the patient way)
+                        const int t2 = __atomic_load_n(&lg->h_done[1], __ATOMIC_ACQUIRE);
+                        have = __atomic_load_n(&lg->h_done[0], __ATOMIC_ACQUIRE) != 0 || (t2 >= 0 && static_cast<uint64_t>(t2) >= enq);
+                        break;
+                    }
+                    if (q != hipErrorNotReady) return fail(ICPX_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+                }
+            }
+        }
+        if (!have) {
+            ICPX_HIP(hipMemcpyAsync(lg->h_done, &dev->st.done, sizeof(int), hipMemcpyDeviceToHost, lg->stream));
+            ICPX_HIP(hipStreamSynchronize(lg->stream));
+        }
         if (lg->h_done[0]) break;
         uint64_t k = static_cast<uint64_t>(chunk);
         if ((crit->has & ICPX_HAS_MAX_ITER) && enq + k > crit->max_iterations)
