@@ -1478,7 +1478,7 @@ int large_create(int dim, int method, const icpx_params& prm, double clock_to_s,
         delete lg;
         return rc;
     }
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&lg->h_done), sizeof(int) * 4, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&lg->h_done), sizeof(int) * 4, hipHostMallocCoherent | hipHostMallocMapped);
     if (e != hipSuccess) {
         grid_destroy(lg->grid);
         delete lg;
@@ -1858,8 +1858,7 @@ int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_
     const double host_offset = std::chrono::duration<double>(lg->init_at - t0).count();
     auto elapsed = [&]() { return host_offset > 0.0 ? host_offset : 0.0; };
     LargeDev* dev = lg->dev.as<LargeDev>();
-    // large_begin already ran setup without a check: evaluate the loop's first should_terminate
-    if (lg->dim == 2)
+    // large_begin already ran setup without a check: evaluate the loop's first should_terminate.
     // progress flags in pinned memory, written by the two kernels that can end the loop; the host polls them
     // (a copy of the flag + a stream synchronisation per chunk left the GPU idle for ~25 us each time)
     struct PollGuard {

@@ -3,6 +3,9 @@
 // host); it only moves pointers across the C ABI.
 #pragma once
 
+#include <stdexcept>
+#include <string>
+
 #include "icp/icp.h"
 
 namespace icp {
@@ -28,7 +31,11 @@ namespace icp {
                       (config.get<int>("apply_guess", 0) ? ICPX_FLAG_APPLY_GUESS : 0);
             p.device = config.get<int>("device", -1);
             const std::string nn = config.get<std::string>("nn", "auto");
-            p.nn_mode = nn == "brute" ? ICPX_NN_BRUTE : nn == "grid" ? ICPX_NN_GRID : ICPX_NN_AUTO;
+            if (nn == "auto") p.nn_mode = ICPX_NN_AUTO;
+            else if (nn == "brute") p.nn_mode = ICPX_NN_BRUTE;
+            else if (nn == "grid") p.nn_mode = ICPX_NN_GRID;
+            else if (nn == "bvh") p.nn_mode = ICPX_NN_BVH;
+            else throw std::invalid_argument("icp::Config nn must be auto, brute, grid or bvh (got \"" + nn + "\")");
             icpx_check(icpx_create(static_cast<int>(Dim), method, &p, &h_));
         }
 

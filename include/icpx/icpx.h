@@ -216,8 +216,9 @@ int icpx_converge_batch_multi(int dim, int method, const icpx_params* params, in
                               const double* guesses, const icpx_criteria* criteria,
                               icpx_state* out_states);
 
-/* icpx_converge_batch for callers that cannot allocate (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arguments
+/* icpx_converge_batch for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc; NOT usable under HIP graph capture as it stands: it copies the host offset arrays and
+ * synchronises the stream before it returns).  NO counterpart in the reference.  Same arguments
  * and results as icpx_converge_batch, but the library calls no hipMalloc / hipFree: all device memory
  * beyond the caller's inputs and outputs (offsets, per-pair states, scheduler words, running clouds,
  * seeds, per-pair grids) lives in one static device array of about 20 MB that every GPU the library
@@ -238,8 +239,9 @@ int icpx_converge_batch_noalloc(int dim, int method, const icpx_params* params, 
 
 /* Development knobs (no reference counterpart).  The ICPX_* environment variables (ICPX_PRUNE,
  * ICPX_FILTER, ICPX_SCHED, ICPX_SCHED_STEPS, ICPX_PRUNE_HANDLES, ICPX_NO_GROUP_SUMS, ICPX_COOP,
- * ICPX_FUSED_SINGLE_MAX, ICPX_GEOM) are read once, when the library is first used; this call
- * changes one afterwards (value NULL = built-in default).  Every setting computes the same
+ * ICPX_GRID_COOP, ICPX_GRID_SEED, ICPX_POLL_DONE, ICPX_FUSE_PREPASS, ICPX_FUSED_SINGLE_MAX,
+ * ICPX_GEOM) are read once, when the library is first used; this call changes one afterwards
+ * (value NULL = built-in default); an unknown name is ICPX_ERR_INVALID.  Every setting computes the same
  * results; they select between kernels.  Not thread-safe against running calls. */
 int icpx_debug_knob(const char* name, const char* value);
 
