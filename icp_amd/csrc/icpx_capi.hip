@@ -161,6 +161,8 @@ constexpr double kFusedSingleMaxWork = 1.1e6;  // measured crossover (n = m = 10
 
 struct PairGeom {
     int qpt, threads, tcap, scap;
+    int64_t m;    // largest target cloud the geometry was sized for
+    bool kd;      // KD kernel (2D vanilla): the kd rule's ties are resolved in the kernel (icpx_kd.h)
     bool filter;  // f32 target copy reserved in LDS (nn_filtered)
     bool prune;   // grid-pruned search (icpx_prune.h): targets ordered by cell, cell table in LDS
     size_t lds;
@@ -205,6 +207,16 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
         }
     }
     r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter, r.prune, r.threads);
+    r.m = m;
+    r.kd = dim == 2 && method == ICPX_VANILLA;
+    // the kd rule (icpx_kd.h): a pair's tree is built in the kernel's LDS on its first tie — by the 2D vanilla kernels
+    // themselves, by the take-over kernel for the 3D methods; both need room for it, and 16-bit positions
+    if (dim == 3 || r.kd) {
+        if (m >= 65536) return false;
+        const size_t kd_lds = pair_lds_bytes_kd(dim, r.tcap, r.kd ? r.scap : 0, m);
+        if (kd_lds > kMaxLds) return false;
+        if (r.kd) r.lds = kd_lds;
+    }
     if (r.lds > kMaxLds) return false;
     if (g) *g = r;
     return true;
@@ -230,8 +242,25 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     pl.cus = di->cus;
     const bool prune = g.prune && pb.tperm && pb.seeds && pb.grids && pb.cstart;
     if (g.prune && !prune) return fail(ICPX_ERR_INVALID, "pruned launch without its permutation buffers");
+    const bool kd_rule = pb.dim == 3 || pb.method == ICPX_VANILLA;
+    if (kd_rule && (!pb.kdnode || !pb.kdpos || !pb.kd_paused)) return fail(ICPX_ERR_INVALID, "launch without the kd rule's buffers");
     if (pb.dim == 2) return prune ? launch_pairs_d2_prune(pb, n_pairs, pl, stream) : launch_pairs_d2_plain(pb, n_pairs, pl, stream);
-    return prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream);
+    // 3D: the kernels only detect the kd rule's ties; a pair that meets one stops there and the KD kernel enqueued
+    // behind takes it over (a launch that finds nothing to do when no pair stopped)
+    ICPX_HIP(hipMemsetAsync(pb.kd_paused, 0, sizeof(int32_t), stream));
+    ICPX_TRY(prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream));
+    PairBatch tb = pb;
+    tb.kd_takeover = 1;
+    tb.sched_state = nullptr;
+    tb.use_filter = 0;
+    tb.lds_sort_cap = 0;
+    tb.do_setup = 0;
+    PairLaunch tl;
+    tl.qpt = 8;
+    tl.threads = 512;
+    tl.lds = pair_lds_bytes_kd(3, g.tcap, 0, g.m);
+    tl.cus = di->cus;
+    return launch_pairs_d3_plain(tb, n_pairs, tl, stream);
 }
 
 // launch of the pre-pass kernel: its dynamic LDS holds the cloud in cell order for the certificate radii; clouds
@@ -276,6 +305,12 @@ int enqueue_prepass(int dim, int64_t n_pairs, int64_t m_max, int64_t m_total, co
     return ICPX_OK;
 }
 
+// [kdnode m][kdpos m] (u16), then 16 bytes whose first word counts the pairs a launch stopped at a tie
+size_t kd_buffer_bytes(int64_t m_total) {
+    const size_t pts = static_cast<size_t>(m_total > 0 ? m_total : 1);
+    return ((4 * pts + 15) & ~static_cast<size_t>(15)) + 16;
+}
+
 icpx_criteria no_criteria() {
     icpx_criteria c;
     std::memset(&c, 0, sizeof(c));
@@ -289,6 +324,7 @@ struct Workspace {
     std::mutex mu;
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
     DevBuf tperm, grids, cstart, hcert;  // grid-pruned search of the batch entry point
+    DevBuf kd, kd_words;                 // kd rule: trees of the target clouds; one counter (16 bytes) per fused run
     GridIndex* grid = nullptr;    // grow-only uniform-grid index of the stand-alone queries
     BvhIndex* bvh = nullptr;      // likewise, ICPX_NN_BVH
     // pinned staging of the offset arrays, so that a stream-ordered call can return before they are consumed
@@ -351,6 +387,7 @@ struct icpx_ctx {
     PairGeom geom{};
     DevBuf src, dst, cur, off, guess, m_point, m_pair, m_cost, pair_tmp, seeds, state, out;
     DevBuf tperm, grids, cstart, hcert;  // grid-pruned search (geom.prune)
+    DevBuf kd;                           // kd rule: [kdnode m][kdpos m] (u16) and the paused-pairs word behind them
     bool use_cert = false;
     LargeIcp* lg = nullptr;
 };
@@ -377,6 +414,7 @@ int upload_pair(icpx_ctx* h, const double* source, int64_t n, const double* targ
     ICPX_TRY(h->seeds.reserve(sizeof(int32_t) * (n > 0 ? n : 1)));
     ICPX_TRY(h->state.reserve(sizeof(PairState)));
     ICPX_TRY(h->out.reserve(sizeof(icpx_state)));
+    ICPX_TRY(h->kd.reserve(kd_buffer_bytes(m)));
     if (n > 0) ICPX_HIP(hipMemcpyAsync(h->src.p, source, sizeof(double) * D * n, hipMemcpyDefault, h->stream));
     if (m > 0) ICPX_HIP(hipMemcpyAsync(h->dst.p, target, sizeof(double) * D * m, hipMemcpyDefault, h->stream));
     int64_t off[4] = {0, n, 0, m};
@@ -413,6 +451,9 @@ void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
     pb.overlap_rate = h->prm.overlap_rate;
     pb.max_distance = h->prm.max_distance;
     pb.clock_to_s = di.clock_to_s;
+    pb.kdnode = h->kd.as<uint16_t>();
+    pb.kdpos = pb.kdnode + (h->m > 0 ? h->m : 1);
+    pb.kd_paused = reinterpret_cast<int32_t*>(h->kd.as<char>() + kd_buffer_bytes(h->m) - 16);
     if (h->geom.prune) {
         pb.tperm = h->tperm.as<uint16_t>();
         pb.grids = h->grids.as<PairGrid>();
@@ -528,6 +569,9 @@ struct BatchScratch {
     PairGrid* grids;    // n_pairs
     uint16_t* cstart;   // n_pairs x kGridTable
     float* hcert;       // m_total certificate radii
+    uint16_t* kdnode;   // m_total: kd rule, the target clouds' trees (in-order layout) ...
+    uint16_t* kdpos;    // m_total: ... and their inverse
+    int32_t* kd_paused; // one word per fused run: pairs stopped at a tie
 };
 
 struct BatchCall {
@@ -593,6 +637,9 @@ int enqueue_fused_run(const BatchCall& c, int64_t lo, int64_t hi, int64_t run_in
         pb.grids = sc.grids + lo;
         pb.cstart = sc.cstart + lo * kGridTable;
     }
+    pb.kdnode = sc.kdnode;
+    pb.kdpos = sc.kdpos;
+    pb.kd_paused = sc.kd_paused + 4 * run_index;
     pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     PairGeom g = geom;
     return launch_pairs(pb, cnt, g, stream);
@@ -757,6 +804,8 @@ int converge_batch_impl(int dim, int method, const icpx_params* params, int64_t 
         ICPX_TRY(ws.grids.reserve(sizeof(PairGrid) * n_pairs));
         ICPX_TRY(ws.cstart.reserve(sizeof(uint16_t) * kGridTable * n_pairs));
         ICPX_TRY(ws.hcert.reserve(sizeof(float) * (m_total > 0 ? m_total : 1)));
+        ICPX_TRY(ws.kd.reserve(kd_buffer_bytes(m_total)));
+        ICPX_TRY(ws.kd_words.reserve(16 * runs.size()));
     }
     BatchScratch sc;
     sc.soff = ws.soff.as<int64_t>();
@@ -769,6 +818,9 @@ int converge_batch_impl(int dim, int method, const icpx_params* params, int64_t 
     sc.grids = ws.grids.as<PairGrid>();
     sc.cstart = ws.cstart.as<uint16_t>();
     sc.hcert = ws.hcert.as<float>();
+    sc.kdnode = ws.kd.as<uint16_t>();
+    sc.kdpos = sc.kdnode ? sc.kdnode + (m_total > 0 ? m_total : 1) : nullptr;
+    sc.kd_paused = ws.kd_words.as<int32_t>();
 
     int64_t run_index = 0;
     for (const BatchRun& r : runs) {
@@ -917,7 +969,9 @@ constexpr size_t kScrTperm = kScrSeeds + align256(sizeof(int32_t) * kNoAllocMaxP
 constexpr size_t kScrGrids = kScrTperm + align256(sizeof(uint16_t) * kNoAllocMaxPoints);
 constexpr size_t kScrCstart = kScrGrids + align256(sizeof(PairGrid) * kNoAllocMaxPairs);
 constexpr size_t kScrHcert = kScrCstart + align256(sizeof(uint16_t) * kGridTable * kNoAllocMaxPairs);
-constexpr size_t kScratchBytes = kScrHcert + align256(sizeof(float) * kNoAllocMaxPoints);
+constexpr size_t kScrKd = kScrHcert + align256(sizeof(float) * kNoAllocMaxPoints);
+constexpr size_t kScrKdWords = kScrKd + align256(sizeof(uint16_t) * 2 * kNoAllocMaxPoints);
+constexpr size_t kScratchBytes = kScrKdWords + align256(16 * kNoAllocMaxPairs);
 
 // Scratch of icpx_converge_batch_noalloc: every GPU the library runs on holds its own copy of this array
 // (about 20 MB) until the process ends.  In host code the NAME is only a stand-in; the device address
@@ -1017,6 +1071,9 @@ int converge_batch_noalloc_impl(int dim, int method, const icpx_params* params, 
     sc.grids = reinterpret_cast<PairGrid*>(ptr + kScrGrids);
     sc.cstart = reinterpret_cast<uint16_t*>(ptr + kScrCstart);
     sc.hcert = reinterpret_cast<float*>(ptr + kScrHcert);
+    sc.kdnode = reinterpret_cast<uint16_t*>(ptr + kScrKd);
+    sc.kdpos = sc.kdnode + kNoAllocMaxPoints;
+    sc.kd_paused = reinterpret_cast<int32_t*>(ptr + kScrKdWords);
     // everything the kernels expect to start from zero is cleared by them or here: PairState, running
     // clouds, seeds, grids and tables are written before they are read (setup / pre-pass); the scheduler
     // words are cleared by launch_one with hipMemsetAsync
@@ -1102,7 +1159,7 @@ int icpx_destroy(icpx_handle h) {
     (void)g.enter(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->src, &h->dst, &h->cur, &h->off, &h->guess, &h->m_point, &h->m_pair,
-                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart, &h->hcert})
+                      &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart, &h->hcert, &h->kd})
         b->release();
     if (h->lg) large_destroy(h->lg);
     delete h;

@@ -7,6 +7,7 @@
 // tile origin in the tiled kernel); all (d2, index) comparisons use the cloud index.
 #pragma once
 
+#include "icpx_kd.h"
 #include "icpx_math.h"
 
 namespace icpx {
@@ -20,6 +21,7 @@ struct LdsView {
     uint32_t* sval;  // sort values
     float* tf[3];    // f32 copy of the target SoA (candidate filter), null when not reserved
     int j0;          // cloud index of LDS slot 0
+    const double* cloud = nullptr;  // KD searches: the whole target cloud (AoS, global), to tell coincident targets from ties
 };
 
 // brute-force NN of QPT register-resident queries against the LDS target cloud.
@@ -33,14 +35,18 @@ struct LdsView {
 // operations, same bits) and taking the lowest j that equals the minimum.  This costs 9.5 (3D) /
 // 6.5 (2D) VALU instructions per pair instead of 12 / 9 with a per-target compare-and-select.
 // `m4` is m rounded up to a multiple of 4; LDS slots [m, m4) hold +inf (never selected).
-template <int D, int QPT>
+// KD (icpx_kd.h): tie[k] reports whether another target lies within kKdNearUlps of the minimum — the second smallest
+// block minimum is carried along (two more instructions per block), the winning block is counted at the end.
+template <int D, int QPT, bool KD = false>
 ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, double (&best)[QPT],
-                     int (&bidx)[QPT]) {
+                     int (&bidx)[QPT], bool* tie = nullptr) {
     int bblk[QPT];
+    double b2[KD ? QPT : 1];
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
         best[k] = __builtin_inf();
         bblk[k] = 0;
+        if (KD) b2[k] = __builtin_inf();
     }
     for (int jb = 0; jb < m4; jb += 4) {
         double tc[D][4];
@@ -64,13 +70,14 @@ ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, dou
             }
             double mm = __builtin_fmin(__builtin_fmin(dist[0], dist[1]), __builtin_fmin(dist[2], dist[3]));
             bool lt = mm < best[k];
+            if (KD) b2[k] = __builtin_fmin(b2[k], __builtin_fmax(best[k], mm));  // second smallest block minimum
             best[k] = __builtin_fmin(best[k], mm);
             bblk[k] = lt ? jb : bblk[k];
         }
     }
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
-        int idx = 0;
+        int idx = 0, near = 0;
         if (best[k] < __builtin_inf()) {
 #pragma unroll
             for (int u = 3; u >= 0; u--) {
@@ -82,9 +89,11 @@ ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, dou
                     acc = acc + df * df;
                 }
                 idx = acc == best[k] ? bblk[k] + u : idx;
+                if (KD) near += kd_near(acc, best[k]) ? 1 : 0;
             }
         }
         bidx[k] = idx;
+        if (KD) tie[k] = best[k] < __builtin_inf() && (near > 1 || kd_near(b2[k], best[k]));
     }
 }
 
@@ -153,20 +162,25 @@ ICPX_DEV float filter_threshold(double d2max, float qn_lo, float e_dist, float e
 
 // exact (d2, j) update of one query against the four targets of block `blk` (lanes with blk < 0
 // idle); j counts in the cloud (L.j0 + slot)
-template <int D>
-ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, double& best, int& bidx) {
+// TIES (icpx_kd.h): *tie becomes true when another, non-coincident target lies within kKdNearUlps of the best
+template <int D, bool TIES = false>
+ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, double& best, int& bidx, bool* tie = nullptr) {
     const bool act = blk >= 0;
     const int jb = act ? blk : 0;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        double df = L.t[0][jb + u] - q[0];
+        double c[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) c[d] = L.t[d][jb + u];
+        double df = c[0] - q[0];
         double acc = df * df;
 #pragma unroll
         for (int d = 1; d < D; d++) {
-            df = L.t[d][jb + u] - q[d];
+            df = c[d] - q[d];
             acc = acc + df * df;
         }
         const int j = L.j0 + jb + u;
+        if (TIES) *tie = *tie || kd_tie_check<D>(act, acc, j, c, L.cloud, best, bidx);
         bool better = act && (acc < best || (acc == best && j < bidx));
         best = better ? acc : best;
         bidx = better ? j : bidx;
@@ -350,19 +364,23 @@ ICPX_DEV void seed_bound(const double (&q)[QPT][D], const LdsView<D>& L, int m, 
 // at a time; candidate blocks are evaluated exactly and every improvement tightens the
 // threshold.  One pending block per query slot is kept in a register; a second candidate for the
 // same slot flushes the first (wave-wide).  Waves with unusable coordinates take nn_lds.
-template <int D, int QPT>
+// TIES: tie[k] |= another non-coincident target within kKdNearUlps of slot k's minimum (icpx_kd.h)
+template <int D, int QPT, bool TIES = false>
 ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4, const FilterFrame& F,
-                          double (&best)[QPT], int (&bidx)[QPT]) {
+                          double (&best)[QPT], int (&bidx)[QPT], bool* tie = nullptr) {
     float q2[QPT][D], qn[QPT], e_dist, e_val;
     const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
     if (__any(!ok)) {
         double lb[QPT];
         int li[QPT];
-        nn_lds<D, QPT>(q, L, m4, lb, li);
+        bool lt[TIES ? QPT : 1];
+        nn_lds<D, QPT, TIES>(q, L, m4, lb, li, TIES ? lt : nullptr);
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
             const int j = L.j0 + li[k];
             const bool take = lb[k] < best[k] || (lb[k] == best[k] && j < bidx[k]);
+            // (coincident targets are not told apart here: a flag too many only costs the resolution's time)
+            if (TIES) tie[k] = tie[k] || lt[k] || (j != bidx[k] && lb[k] < __builtin_inf() && kd_near(lb[k], best[k]));
             best[k] = take ? lb[k] : best[k];
             bidx[k] = take ? j : bidx[k];
         }
@@ -396,7 +414,7 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4
                     if (__any(cand[g] && pend[k] >= 0)) {
                         ICPX_STAT(1, 1);
                         double before = best[k];
-                        exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
+                        exact_block<D, TIES>(q[k], L, pend[k], best[k], bidx[k], TIES ? &tie[k] : nullptr);
                         pend[k] = -1;
                         if (best[k] < before) thr[k] = filter_threshold(best[k], qn[k], e_dist, e_val);
                     }
@@ -407,7 +425,7 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4
     }
 #pragma unroll
     for (int k = 0; k < QPT; k++)
-        if (__any(pend[k] >= 0)) exact_block<D>(q[k], L, pend[k], best[k], bidx[k]);
+        if (__any(pend[k] >= 0)) exact_block<D, TIES>(q[k], L, pend[k], best[k], bidx[k], TIES ? &tie[k] : nullptr);
 }
 
 // Wave-cooperative rescan of single queries: for every lane whose flag is set, the wave takes
@@ -415,9 +433,9 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4
 // its candidate blocks exactly; a butterfly over (d2, j) leaves the lexicographic minimum, which
 // the owning lane keeps.  1024 blocks cost 16 steps instead of a 1024-step scan with one useful
 // lane.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D], float thr, const LdsView<D>& L,
-                          int m4, double& best, int& bidx) {
+                          int m4, double& best, int& bidx, bool* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     unsigned long long mask = __ballot(flag);
     while (mask) {
@@ -433,22 +451,27 @@ ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D],
         const float thr_b = __shfl(thr, src);
         double bb = __builtin_inf();
         int bi = 0x7fffffff;
+        bool lt = false;
         for (int jb = lane * 4; jb < m4; jb += 256) {
             f32x4 tc[D], tn;
             load_filter_block<D>(L, jb, tc, tn);
-            if (!(block_filter_min<D>(tc, tn, q2b) > thr_b)) exact_block<D>(qb, L, jb, bb, bi);
+            if (!(block_filter_min<D>(tc, tn, q2b) > thr_b)) exact_block<D, TIES>(qb, L, jb, bb, bi, TIES ? &lt : nullptr);
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             double ob = __shfl_xor(bb, o);
             int oi = __shfl_xor(bi, o);
             bool take = ob < bb || (ob == bb && oi < bi);
+            // (two lanes' minima within the tie range: flagged without the coincidence test of nn_take)
+            if (TIES) lt = lt || (oi != 0x7fffffff && bi != 0x7fffffff && oi != bi && ob < __builtin_inf() && kd_near(ob, bb));
             bb = take ? ob : bb;
             bi = take ? oi : bi;
         }
+        if (TIES) lt = __any(lt);
         if (lane == src && bb < __builtin_inf()) {
             best = bb;
             bidx = bi;
+            if (TIES) *tie = lt;  // the rescan saw every target that close: its verdict replaces the winning block's
         }
     }
 }
@@ -460,13 +483,13 @@ ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D],
 // The winning block is evaluated exactly; if b2 lies above the threshold of that exact best, no
 // other block can hold a target with d2 <= best and the search is complete.  Otherwise — exact
 // ties and near-ties inside the error budget — the query is rescanned cooperatively (coop_rescan).
-template <int D, int QPT>
+template <int D, int QPT, bool TIES = false>
 ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m4, const FilterFrame& F,
-                        double (&best)[QPT], int (&bidx)[QPT]) {
+                        double (&best)[QPT], int (&bidx)[QPT], bool* tie = nullptr) {
     float q2[QPT][D], qn[QPT], e_dist, e_val;
     const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
     if (__any(!ok)) {
-        nn_lds<D, QPT>(q, L, m4, best, bidx);
+        nn_lds<D, QPT, TIES>(q, L, m4, best, bidx, tie);
 #pragma unroll
         for (int k = 0; k < QPT; k++) bidx[k] += L.j0;
         return;
@@ -498,14 +521,15 @@ ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m4, 
     for (int k = 0; k < QPT; k++) {
         best[k] = __builtin_inf();
         bidx[k] = 0x7fffffff;
-        exact_block<D>(q[k], L, blk[k], best[k], bidx[k]);
+        if (TIES) tie[k] = false;
+        exact_block<D, TIES>(q[k], L, blk[k], best[k], bidx[k], TIES ? &tie[k] : nullptr);
         // near-ties (about 0.15 % of the queries on uniform clouds): cooperative rescan
         const float thr = filter_threshold(best[k], qn[k], e_dist, e_val);
         const bool again = !(b2[k] > thr);
         ICPX_STAT(3, __popcll(__ballot(again)));
         if (__any(again)) {
             ICPX_STAT(4, 1);
-            coop_rescan<D>(again, q[k], q2[k], thr, L, m4, best[k], bidx[k]);
+            coop_rescan<D, TIES>(again, q[k], q2[k], thr, L, m4, best[k], bidx[k], TIES ? &tie[k] : nullptr);
         }
     }
 }

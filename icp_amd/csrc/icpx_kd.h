@@ -1,0 +1,211 @@
+// icpx_kd.h — the reference kd-tree's tie rule on top of the exact searches (device side).
+//
+// The reference's kd-tree methods (Vanilla 2D: vanilla.cpp:68-88; Vanilla3d / Trimmed3d: vanilla_3d.cpp:30-45,
+// trimmed_3d.cpp:36-51) take the neighbour from KdTree::search (include/algo/kdtree.h:79-89,132-154), which compares
+// sqrt(d2) with strict < and keeps the FIRST node it visits, children near side first.  Pruning never hides that node
+// (DESIGN.md section 3), so its answer is
+//     among the targets whose sqrt(d2) equals the minimal sqrt(d2), bit for bit, the one that comes first in the
+//     near-child-first pre-order of the tree for this query.
+// Every search of this library finds the (d2, index) minimum; almost always that target is alone at its sqrt(d2) and
+// both rules name it.  The searches therefore only DETECT the other case — another target within kKdNearUlps of the
+// best d2 (kd_near; at most four consecutive doubles share one square root) — and the rare flagged queries are
+// resolved here: tied set by sqrt(d2), pre-order key of every member (kd_key), smallest key wins, then the lowest
+// index among the targets coincident with the winner (which of those the reference returns is its std::nth_element's
+// choice).
+//
+// The tree is the median-split tree of kdtree.h:96-116 — node of the range [lo, hi) = element (n - 1) / 2 of the
+// subset ordered by the split coordinate, axis = depth % dim — stored IN ORDER: node[p] is the target at in-order
+// position p, pos[t] its inverse; the node of [lo, hi) sits at lo + (hi - lo - 1) / 2.  Equal coordinates are ordered
+// by index (the reference leaves them to nth_element: implementation-defined there).
+// oracle/icp_oracle.cpp (KdCanon) states the same rule on the CPU, in two formulations.
+#pragma once
+
+#include "icpx_math.h"
+
+namespace icpx {
+
+constexpr unsigned long long kKdNearUlps = 4;
+
+// |bits(a) - bits(b)| <= kKdNearUlps for squared distances (non-negative: bit patterns order like the values)
+ICPX_DEV bool kd_near(double a, double b) {
+    const long long x = __double_as_longlong(a), y = __double_as_longlong(b);
+    const unsigned long long d = x > y ? static_cast<unsigned long long>(x - y) : static_cast<unsigned long long>(y - x);
+    return d <= kKdNearUlps;
+}
+
+// order-preserving f64 -> u64 (a total order; the tree's coordinate order)
+ICPX_DEV unsigned long long kd_ord_key(double v) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+
+template <typename I>
+struct KdView {
+    const I* node;      // [m] target at in-order position p
+    const I* pos;       // [m] in-order position of target t
+    const double* pts;  // the target cloud (AoS, cloud order, global memory)
+    int m;
+};
+
+// Pre-order key of target t for query q: two bits per level from the root — 0 this node, 1 the child on the query's
+// side (kdtree.h:146: left iff q[axis] < node[axis]), 2 the other child.  Smaller key = visited earlier.
+template <int D, typename I>
+ICPX_DEV unsigned long long kd_key(const KdView<I>& kd, const double (&q)[D], const int t) {
+    const int P = static_cast<int>(kd.pos[t]);
+    int lo = 0, hi = kd.m, axis = 0;
+    unsigned long long k = 0;
+    for (int depth = 0; depth < 31; depth++) {
+        const int mid = lo + ((hi - lo - 1) >> 1);
+        if (P == mid) break;
+        const double c = kd.pts[static_cast<int64_t>(kd.node[mid]) * D + axis];
+        double qa = q[0];
+#pragma unroll
+        for (int d = 1; d < D; d++) qa = axis == d ? q[d] : qa;
+        const bool near_left = qa < c, go_left = P < mid;
+        k |= static_cast<unsigned long long>(go_left == near_left ? 1 : 2) << (60 - 2 * depth);
+        if (go_left) hi = mid;
+        else lo = mid + 1;
+        axis = axis + 1 == D ? 0 : axis + 1;
+    }
+    return k;
+}
+
+// Is the candidate (dist, j; coordinates c[0..D)) a tie partner of the current best (best, bidx)?  Another target
+// within kKdNearUlps of it — unless the two coincide (cloud: the targets in cloud order, to look the best's coordinates
+// up; a rare branch; null: not checked).  bidx == 0x7fffffff: no best yet.  No false negatives over a whole search:
+// whichever of two such targets is evaluated second sees the first (or something closer still) as the best.
+template <int D>
+ICPX_DEV bool kd_tie_check(const bool valid, const double dist, const int j, const double* c,
+                           const double* __restrict__ cloud, const double best, const int bidx) {
+    bool near = valid && bidx != 0x7fffffff && j != bidx && dist < __builtin_inf() && kd_near(dist, best);
+    if (near && dist == best && cloud != nullptr) {
+        bool same = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) same = same && cloud[static_cast<int64_t>(bidx) * D + d] == c[d];
+        near = !same;
+    }
+    return near;
+}
+
+// (best, bidx) <- (d2, index) minimum with the candidate; KD: tie |= kd_tie_check
+template <bool KD, int D>
+ICPX_DEV void nn_take(const bool valid, const double dist, const int j, const double* c, const double* __restrict__ cloud,
+                      double& best, int& bidx, bool& tie) {
+    const bool take = valid && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
+    if (KD) tie = tie || kd_tie_check<D>(valid, dist, j, c, cloud, best, bidx);
+    best = take ? dist : best;
+    bidx = take ? j : bidx;
+}
+
+// Resolution of flagged queries, one workgroup per query, scanning the whole cloud (multi-kernel path and the
+// stand-alone query: flagged queries are rare, and this needs nothing from the engine that found the minimum).
+// list[0..count): query indices.  MODE as lg_nn_kernel (0: queries = cur, 1: src, 2 / 3: transform * src).
+template <int D>
+ICPX_DEV void kd_query_of(const int mode, const double* __restrict__ src, const double* __restrict__ cur, const double* xf,
+                          const int64_t i, double (&q)[D]) {
+    if (mode == 0) {
+#pragma unroll
+        for (int d = 0; d < D; d++) q[d] = cur[i * D + d];
+    } else if (mode == 1) {
+#pragma unroll
+        for (int d = 0; d < D; d++) q[d] = src[i * D + d];
+    } else {
+        Xf<D> X;
+#pragma unroll
+        for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = xf[e];
+        const XfRows<D> xr = xf_rows<D>(X);
+        double p[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) p[d] = src[i * D + d];
+        xf_apply<D>(xr, p, q);
+    }
+}
+
+constexpr int kKdResolveThreads = 256;
+
+// count: device word (number of flagged queries); nb_idx: in = the (d2, index) minimum's target, out = the rule's.
+// nb_d2 (may be null): receives nothing new (all tied targets share sqrt(d2)); the minimum's d2 is recomputed here.
+template <int D>
+__global__ void __launch_bounds__(kKdResolveThreads)
+kd_resolve_kernel(const int* __restrict__ count, const uint32_t* __restrict__ list, const int mode,
+                  const double* __restrict__ src, const double* __restrict__ cur, const double* __restrict__ xf,
+                  const KdView<uint32_t> kd, int64_t* __restrict__ nb_idx) {
+    __shared__ unsigned long long s_key[kKdResolveThreads / 64];
+    __shared__ int s_idx[kKdResolveThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int W = kKdResolveThreads / 64;
+    const int total = *count;
+    for (int e = blockIdx.x; e < total; e += gridDim.x) {
+        const int64_t i = list[e];
+        double q[D];
+        kd_query_of<D>(mode, src, cur, xf, i, q);
+        // the minimal d2 (the engines' answer, recomputed: nb_idx names a target that attains it)
+        const int64_t b0 = nb_idx[i];
+        double best = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const double df = kd.pts[b0 * D + d] - q[d];
+            best = d == 0 ? df * df : best + df * df;
+        }
+        if (!(best < __builtin_inf())) continue;  // (uniform) nothing finite: the (d2, index) convention stands
+        const double s = __builtin_sqrt(best);
+        unsigned long long mk = ~0ull;
+        int mi = 0x7fffffff;
+        for (int j = tid; j < kd.m; j += kKdResolveThreads) {
+            double df = kd.pts[static_cast<int64_t>(j) * D] - q[0];
+            double acc = df * df;
+#pragma unroll
+            for (int d = 1; d < D; d++) {
+                df = kd.pts[static_cast<int64_t>(j) * D + d] - q[d];
+                acc = acc + df * df;
+            }
+            if (kd_near(acc, best) && __builtin_sqrt(acc) == s) {
+                const unsigned long long k = kd_key<D, uint32_t>(kd, q, j);
+                if (k < mk) {
+                    mk = k;
+                    mi = j;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long ok = __shfl_xor(mk, o);
+            const int oi = __shfl_xor(mi, o);
+            const bool take = ok < mk;
+            mk = take ? ok : mk;
+            mi = take ? oi : mi;
+        }
+        __syncthreads();  // (the previous entry's reads of the shared words are done)
+        if (lane == 0) {
+            s_key[wave] = mk;
+            s_idx[wave] = mi;
+        }
+        __syncthreads();
+        for (int w = 0; w < W; w++) {
+            const bool take = s_key[w] < mk;
+            mk = take ? s_key[w] : mk;
+            mi = take ? s_idx[w] : mi;
+        }
+        if (mi == 0x7fffffff) continue;  // (uniform; cannot happen: the minimum itself is in the tied set)
+        // the lowest index among the targets coincident with the winner
+        double w[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) w[d] = kd.pts[static_cast<int64_t>(mi) * D + d];
+        int lowest = mi;
+        for (int j = tid; j < kd.m && j < mi; j += kKdResolveThreads) {
+            bool same = true;
+#pragma unroll
+            for (int d = 0; d < D; d++) same = same && kd.pts[static_cast<int64_t>(j) * D + d] == w[d];
+            lowest = (same && j < lowest) ? j : lowest;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) lowest = min(lowest, __shfl_xor(lowest, o));
+        __syncthreads();
+        if (lane == 0) s_idx[wave] = lowest;
+        __syncthreads();
+        for (int ww = 0; ww < W; ww++) lowest = min(lowest, s_idx[ww]);
+        if (tid == 0) nb_idx[i] = lowest;
+    }
+}
+
+}  // namespace icpx

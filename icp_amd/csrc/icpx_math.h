@@ -399,7 +399,7 @@ struct PairState {
     int32_t have_last;
     int32_t done;
     uint64_t start_clock;  // wall_clock64() when converge started
-    uint64_t _pad;
+    uint64_t kd_flags;     // kd-tree tie rule (icpx_kd.h): bit 0 the pair's tree is built, bit 1 stopped at a tie (take-over pending)
 };
 
 // ICPDriver::should_terminate (driver.h:154-222).  elapsed_s: seconds since converge() began.

@@ -24,6 +24,7 @@
 #endif
 
 #include "icpx_filter.h"
+#include "icpx_kd_lds.h"
 #include "icpx_math.h"
 #include "icpx_prune.h"
 
@@ -85,6 +86,12 @@ struct PairBatch {
     float* hcert;              // m_total: certificate radius of the target at LDS slot j of its pair; null = none
     int32_t prepare;           // the setup visit of a pair computes the four above itself (prepare_target_grid);
                                // 0: pair_perm_kernel has run before this launch
+    // the kd-tree tie rule (icpx_kd.h): per target cloud its tree in in-order layout, built on a pair's first tie
+    uint16_t* kdnode;          // m_total
+    uint16_t* kdpos;           // m_total
+    int32_t* kd_paused;        // one word: pairs that a kernel without the rule's resolution paused at a tie
+                               // (PairState::kd_flags bit 1); the KD kernel launched behind it takes them over
+    int32_t kd_takeover;       // this launch is that KD kernel: only paused pairs run, from where they stopped
 };
 
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
@@ -96,16 +103,18 @@ inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int 
 template <int D>
 ICPX_DEV LdsView<D> carve(double* base, int tcap, int scap, int filter) {
     LdsView<D> v;
+    // group sums and broadcast area first: everything behind them is the target cloud and search scratch, which the
+    // tree build of the kd rule (kd_build_lds) may take over as one piece (the cloud is restaged afterwards)
     double* p = base;
+    v.gs = p;
+    p += kGsValues * kGsStride;
+    v.bc = p;
+    p += kBcDoubles;
     for (int d = 0; d < D; d++) {
         v.t[d] = p;
         p += tcap;
     }
     if (D == 2) v.t[2] = nullptr;
-    v.gs = p;
-    p += kGsValues * kGsStride;
-    v.bc = p;
-    p += kBcDoubles;
     v.skey = reinterpret_cast<uint64_t*>(p);
     v.sval = reinterpret_cast<uint32_t*>(v.skey + scap);
     float* f = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + pair_lds_filter_offset(D, tcap, scap));
@@ -121,6 +130,12 @@ inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter, bool prun
         return pair_lds_filter_offset(dim, tcap, scap) + sizeof(uint16_t) * kGridTable +
                static_cast<size_t>(threads / 64) * coop_wave_bytes(dim);
     return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0);
+}
+// KD kernels: at least the tree build's scratch behind the group sums and the broadcast area
+inline size_t pair_lds_bytes_kd(int dim, int tcap, int scap, int64_t m) {
+    const size_t plain = pair_lds_bytes(dim, tcap, scap, false);
+    const size_t build = sizeof(double) * (kGsValues * kGsStride + kBcDoubles) + kd_build_bytes(dim, m);
+    return plain > build ? plain : build;
 }
 
 // TREE64 sum of NV values per point.  f(k, v) is contribution v of point tid + k*T (exactly +0.0 where the
@@ -657,12 +672,29 @@ struct SlotVecI {
     }
 };
 
+// OR over the workgroup through one LDS word that thread 0 cleared at least one barrier ago (the pair bodies clear
+// it at the top of every trip of the converge loop).  (HIP's own barrier-with-OR reserves 256 bytes of static LDS.)
+ICPX_DEV bool block_any(const bool v, int* word) {
+    if (v) *word = 1;
+    __syncthreads();
+    return *word != 0;
+}
+
 // One visit of pair p: optional begin()/setup(), then up to max_steps iterations of the converge
 // loop.  Returns 1 when should_terminate fired (pair finished), 2 when it paused at max_steps.
 // (The brute-force body: handles and small clouds.  Batches run pair_body_pruned, icpx_pair_pruned.h.)
-template <int D, int METHOD, int QPT>
+// The kd-tree methods (vanilla 2D, both 3D) follow the reference tree's tie rule (icpx_kd.h):
+//   KD kernels  search with the plain f64 scan (nn_lds<KD>), build the pair's tree on its first flagged query and
+//               resolve flagged queries in place: every 2D vanilla kernel (it searches once per begin), and the 3D
+//               take-over kernel;
+//   3D kernels without it only detect: a pair with a flagged query stops BEFORE that iteration changes anything
+//               (PairState::kd_flags bit 1, exit as if finished) and the KD kernel launched behind takes it over.
+template <int D, int METHOD, int QPT, bool KD>
 ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps,
                        double* lds_raw) {
+    constexpr bool kKdRule = D == 3 || METHOD == ICPX_VANILLA;  // methods whose neighbour comes from KdTree::search
+    static_assert(!KD || kKdRule, "KD kernels exist for the kd-tree methods only");
+    constexpr bool TIES = kKdRule && !KD;                        // detect only
     constexpr int L1 = D + 1;
     constexpr int XN = L1 * L1;
     const int T = blockDim.x;
@@ -673,8 +705,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     const double* __restrict__ src = pb.src + s0 * D;
     const double* __restrict__ dst = pb.dst + d0 * D;
     PairState* st = pb.states + p;
-    const bool filter = pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
+    const bool filter = !KD && pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
     LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
+    L.cloud = dst;
     const bool empty = (n == 0 || m == 0);
 
     // ---- stage the target cloud into LDS as SoA (+ f32 copy about the bounding-box centre) ----
@@ -718,10 +751,43 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             st->done = 0;
             st->last_cost = 0.0;
             st->start_clock = wall_clock64();
+            st->kd_flags = 0;
         }
         for (int e = 0; e < XN; e++) L.bc[e] = st->transform[e];
+        reinterpret_cast<int*>(L.bc + 41)[0] = do_setup ? 0 : static_cast<int>(st->kd_flags);
+        reinterpret_cast<int*>(L.bc + 42)[0] = 0;  // block_any's word
     }
     __syncthreads();
+    int* const any_word = reinterpret_cast<int*>(L.bc + 42);
+    // kd rule: is the pair's tree built (bit 0)?  A take-over visit (bit 1 was set by the kernel that stopped at a
+    // tie) resumes INSIDE the loop: that kernel has already evaluated should_terminate and copied state -> last_state
+    bool kd_ready = (reinterpret_cast<int*>(L.bc + 41)[0] & 1) != 0;
+    bool kd_resume = KD && pb.kd_takeover != 0;
+    // KD kernels: flagged queries of one search are resolved here, by the whole workgroup (barriers)
+    auto kd_fix = [&](const double (&q)[QPT][D], const double (&best)[QPT], int (&pair_)[QPT], const bool (&tie)[QPT],
+                      const bool (&valid_)[QPT]) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < QPT; k++) any = any || (tie[k] && valid_[k]);
+        if (!block_any(any, any_word)) return;
+        if (!kd_ready) {
+            kd_build_lds<D, uint16_t>(dst, m, reinterpret_cast<char*>(L.t[0]), pb.kdnode + d0, pb.kdpos + d0);
+            (void)stage_targets<D>(dst, m, (m + 3) & ~3, T, L, false);  // the build used the cloud's place in LDS
+            kd_ready = true;
+            if (tid == 0) st->kd_flags |= 1;
+        }
+        KdView<uint16_t> kd;
+        kd.node = pb.kdnode + d0;
+        kd.pos = pb.kdpos + d0;
+        kd.pts = dst;
+        kd.m = m;
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            int sl = pair_[k];
+            kd_resolve_wave<D, uint16_t>(tie[k] && valid_[k], q[k], best[k], L, m, nullptr, kd, sl);
+            pair_[k] = sl;
+        }
+    };
     // seeds for the filtered search: the previous nearest neighbours.  Trimmed ICP2 has them from
     // setup on; ICP3 after its first iterate; a resumed launch reloads them.
     bool have_seed = false;
@@ -755,8 +821,14 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], q[k]);
             }
             double best[QPT];
-            if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
-            else nn_lds<D, QPT>(q, L, m4, best, pair);
+            if constexpr (KD) {
+                bool tie[QPT];
+                nn_lds<D, QPT, true>(q, L, m4, best, pair, tie);
+                kd_fix(q, best, pair, tie, valid);
+            } else {
+                if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
+                else nn_lds<D, QPT>(q, L, m4, best, pair);
+            }
             have_seed = filter;
 #pragma unroll
             for (int k = 0; k < QPT; k++) {
@@ -790,7 +862,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     while (true) {
         if (tid == 0) {
             int stop = 0;
-            if (pb.check) {
+            if (pb.check && !kd_resume) {
                 double el = pb.host_elapsed_s +
                             static_cast<double>(wall_clock64() - st->start_clock) * pb.clock_to_s;
                 if (should_terminate<D>(pb.crit, *st, el)) {
@@ -799,13 +871,14 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 }
             }
             if (!stop && steps >= max_steps) stop = 2;
-            if (!stop) {
+            if (!stop && !kd_resume) {
                 // last_state = state
                 for (int e = 0; e < XN; e++) st->last_transform[e] = st->transform[e];
                 st->last_cost = st->cost;
                 st->have_last = 1;
             }
             reinterpret_cast<int*>(L.bc + 40)[0] = stop;
+            *any_word = 0;
         }
         __syncthreads();
         int stop = reinterpret_cast<int*>(L.bc + 40)[0];
@@ -813,6 +886,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         exit_code = stop;
         if (stop) break;
         steps++;
+        kd_resume = false;
 
         if (!empty) {
             // ================= iterate() =================
@@ -878,11 +952,34 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++)
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
-                if (have_seed) {
-                    seed_bound<D, QPT>(cur, L, m, best, pair);
-                    nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
-                } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
-                else nn_lds<D, QPT>(cur, L, m4, best, pair);
+                bool tie[QPT];
+#pragma unroll
+                for (int k = 0; k < QPT; k++) tie[k] = false;
+                if constexpr (KD) {
+                    nn_lds<D, QPT, true>(cur, L, m4, best, pair, tie);
+                    kd_fix(cur, best, pair, tie, valid);
+                } else {
+                    if (have_seed) {
+                        seed_bound<D, QPT>(cur, L, m, best, pair);
+                        nn_filtered<D, QPT, TIES>(cur, L, m4, F, best, pair, tie);
+                    } else if (filter) nn_twomin<D, QPT, TIES>(cur, L, m4, F, best, pair, tie);
+                    else nn_lds<D, QPT, TIES>(cur, L, m4, best, pair, tie);
+                    if (TIES) {
+                        bool any = false;
+#pragma unroll
+                        for (int k = 0; k < QPT; k++) any = any || (tie[k] && valid[k]);
+                        if (block_any(any, any_word)) {
+                            // a flagged query: this kernel cannot resolve it.  Nothing of this iteration has been
+                            // stored yet; hand the pair over as it stood before it
+                            if (tid == 0) {
+                                st->kd_flags |= 2;
+                                atomicAdd(pb.kd_paused, 1);
+                            }
+                            exit_code = 1;
+                            break;
+                        }
+                    }
+                }
                 have_seed = filter;
 #pragma unroll
                 for (int k = 0; k < QPT; k++) {
@@ -1044,15 +1141,28 @@ template <int D, int METHOD, int QPT>
 ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps,
                               double* lds_raw);  // icpx_pair_pruned.h
 
-template <int D, int METHOD, int QPT, bool PRUNE>
+template <int D, int METHOD, int QPT, bool PRUNE, bool KD>
 ICPX_DEV int pair_visit(const PairBatch& pb, const int p, const int do_setup, const uint64_t max_steps, double* lds_raw) {
     if constexpr (PRUNE) return pair_body_pruned<D, METHOD, QPT>(pb, p, do_setup, max_steps, lds_raw);
-    else return pair_body<D, METHOD, QPT>(pb, p, do_setup, max_steps, lds_raw);
+    else return pair_body<D, METHOD, QPT, KD>(pb, p, do_setup, max_steps, lds_raw);
 }
 
-template <int D, int METHOD, int QPT, int TMAX, bool PRUNE>
+template <int D, int METHOD, int QPT, int TMAX, bool PRUNE, bool KD>
 __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX, PRUNE)) pair_kernel(const PairBatch pb) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    if constexpr (KD) {
+        if (pb.kd_takeover) {
+            // the KD kernel behind a launch that only detects ties: workgroup b looks after pair b, if that launch
+            // stopped it at a tie; from where it stopped (icpx_pair.h, pair_body)
+            if (__hip_atomic_load(pb.kd_paused, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+            const bool paused = (pb.states[blockIdx.x].kd_flags & 2) != 0;
+            __syncthreads();
+            if (!paused) return;
+            if (threadIdx.x == 0) pb.states[blockIdx.x].kd_flags &= ~static_cast<uint64_t>(2);
+            (void)pair_visit<D, METHOD, QPT, PRUNE, KD>(pb, blockIdx.x, 0, pb.max_steps, lds_raw);
+            return;
+        }
+    }
     // Two ways of handing out pairs, ONE call site of the pair's code (it is large):
     //   plain      workgroup b runs pair b from begin to end;
     //   scheduled  persistent workgroups take iteration-granular tasks (pair, next iterations).
@@ -1130,7 +1240,7 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX, PRUNE)) pai
 #ifdef ICPX_STATS
         const uint64_t stat_t0 = wall_clock64();
 #endif
-        const int code = pair_visit<D, METHOD, QPT, PRUNE>(pb, q, setup, task_steps, lds_raw);
+        const int code = pair_visit<D, METHOD, QPT, PRUNE, KD>(pb, q, setup, task_steps, lds_raw);
         if (!sched) break;
 #ifdef ICPX_STATS
         if (tid == 0) {

@@ -17,9 +17,9 @@
 namespace icpx {
 namespace {
 
-template <int D, int METHOD, int QPT, int TMAX, bool PRUNE>
+template <int D, int METHOD, int QPT, int TMAX, bool PRUNE, bool KD = (D == 2 && METHOD == ICPX_VANILLA)>
 int launch_one(const PairBatch& pb_in, int64_t n_pairs, const PairLaunch& g, hipStream_t stream) {
-    auto kern = pair_kernel<D, METHOD, QPT, TMAX, PRUNE>;
+    auto kern = pair_kernel<D, METHOD, QPT, TMAX, PRUNE, KD>;
     static std::mutex mu;
     static std::unordered_map<int, bool> attr_set;  // per device
     int dev = 0;
@@ -43,8 +43,8 @@ int launch_one(const PairBatch& pb_in, int64_t n_pairs, const PairLaunch& g, hip
         const int64_t resident = static_cast<int64_t>(per_cu > 0 ? per_cu : 1) * g.cus;
         const int force = knobs().sched;  // development knob ICPX_SCHED: 0 = never, 1 = always
         bool use = n_pairs > resident && n_pairs <= 16 * resident && n_pairs < (1 << 20) &&
-                   !(D == 2 && METHOD == ICPX_VANILLA);
-        if (force >= 0) use = force == 1 && n_pairs < (1 << 20) && !(D == 2 && METHOD == ICPX_VANILLA);
+                   !(D == 2 && METHOD == ICPX_VANILLA) && !pb.kd_takeover;
+        if (force >= 0) use = force == 1 && n_pairs < (1 << 20) && !(D == 2 && METHOD == ICPX_VANILLA) && !pb.kd_takeover;
         if (use) {
             blocks = n_pairs < resident ? n_pairs : resident;
             pb.n_pairs = static_cast<int32_t>(n_pairs);
@@ -91,6 +91,16 @@ int launch_dm(const PairBatch& pb, int64_t n_pairs, const PairLaunch& g, hipStre
 int ICPX_INST_NAME(ICPX_INST_DIM)(const PairBatch& pb, int64_t n_pairs, const PairLaunch& g, hipStream_t stream) {
     constexpr int D = ICPX_INST_DIM;
     constexpr bool PRUNE = ICPX_INST_PRUNE != 0;
+    if (pb.kd_takeover) {
+        // the 3D kernel that resolves the kd rule's ties (one geometry: any n <= 4096), behind a launch that only detects them
+        if constexpr (D == 3 && !PRUNE) {
+            if (g.qpt != 8 || g.threads != 512) return fail(ICPX_ERR_INVALID, "the kd take-over kernel runs 8 queries per lane x 512 threads");
+            if (pb.method == ICPX_VANILLA) return launch_one<3, ICPX_VANILLA, 8, 512, false, true>(pb, n_pairs, g, stream);
+            return launch_one<3, ICPX_TRIMMED, 8, 512, false, true>(pb, n_pairs, g, stream);
+        } else {
+            return fail(ICPX_ERR_INVALID, "no kd take-over kernel in this object");
+        }
+    }
     if (pb.method == ICPX_VANILLA) {
         // 2D vanilla searches once per begin: it has no filtered (hence no pruned) search
         if constexpr (D == 2 && PRUNE) return fail(ICPX_ERR_INVALID, "no pruned kernel for 2D vanilla");

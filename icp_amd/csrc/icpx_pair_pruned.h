@@ -115,7 +115,7 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
             ls->cost = 0.0;
             ls->last_cost = 0.0;
             ls->start_clock = wall_clock64();
-            ls->_pad = 0;
+            ls->kd_flags = 0;
         } else {
             *ls = *st;
         }
@@ -141,6 +141,8 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
     // The correspondence step: for every slot k (runtime loop, one copy of the code) the query is
     // c[k] (3D, vanilla_3d.cpp:30-45) or X * a[k] (2D, trimmed.cpp:41,95-109); results into pv / costv.
     // selm: 3D trimmed — bit k set when the neighbour is within max_distance (trimmed_3d.cpp:98).
+    constexpr bool TIES = D == 3;  // the kd-tree methods: detect the tie rule's cases (icpx_kd.h); 2D here is trimmed (brute-force rule)
+    bool kd_tie = false;
     auto search = [&](const bool seeded, int& selm) __attribute__((always_inline)) {
         const XfRows<D> xr = xf_rows<D>(X);
         selm = 0;
@@ -172,8 +174,8 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
             ICPX_STAT(30, __popcll(__ballot(v && !todo)));  // ... of which by a certified seed (no search)
             ICPX_STAT(31, __popcll(__ballot(v && seeded))); // ... seed evaluations (one distance each)
             if (__any(todo)) {
-                if (coop) nn_coop_slot<D>(q1[0], todo, seeded, L, P, CS, b1[0], s1[0]);
-                else nn_grid_slot<D>(q1[0], todo, seeded, L, P, b1[0], s1[0]);
+                if (coop) nn_coop_slot<D, TIES>(q1[0], todo, seeded, L, P, CS, b1[0], s1[0], &kd_tie);
+                else nn_grid_slot<D, TIES>(q1[0], todo, seeded, L, P, b1[0], s1[0], &kd_tie);
             }
             pv.d[0] = v ? s1[0] : 0;
             if (D == 2) {
@@ -230,6 +232,7 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
                 ls->have_last = 1;
             }
             reinterpret_cast<int*>(L.bc + 40)[0] = stop;
+            reinterpret_cast<int*>(L.bc + 42)[0] = 0;  // block_any's word
         }
         __syncthreads();
         const int stop = reinterpret_cast<int*>(L.bc + 40)[0];
@@ -249,6 +252,18 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
 #endif
             search(have_seed, selm);
             have_seed = true;
+            if (TIES) {
+                if (block_any(kd_tie, reinterpret_cast<int*>(L.bc + 42))) {
+                    // a query met the kd rule's tie case, which this kernel only detects: the pair stops here, as it stood
+                    // before this iteration (nothing of it has been stored), and the KD kernel behind takes it over
+                    if (tid == 0) {
+                        ls->kd_flags |= 2;
+                        atomicAdd(pb.kd_paused, 1);
+                    }
+                    exit_code = 1;
+                    break;
+                }
+            }
             const XfRows<D> xr = xf_rows<D>(X);
             if (D == 2) {
                 // trimming step, trimmed.cpp:55-58: in the order (cost, point) keep the first new_n; only the

@@ -63,8 +63,22 @@ inline __host__ __device__ int grid_cells_per_axis(int dim, int m) {
 
 // Exact scan of all targets: same outcome as nn_lds on the unpermuted cloud, including its
 // conventions for non-finite distances (nothing below +inf -> cloud index 0).
+// near-tie test of the kd rule between the candidate in slot j (d2 = acc) and the best so far (icpx_kd.h): another
+// target within kKdNearUlps of it that does not coincide with it
 template <int D>
-ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const GridView& P, double& best, int& bslot) {
+ICPX_DEV bool slot_tie(const bool act, const double acc, const int j, const double best, const int bslot, const LdsView<D>& L) {
+    bool near = act && bslot >= 0 && j != bslot && acc < __builtin_inf() && kd_near(acc, best);
+    if (near && acc == best) {
+        bool same = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) same = same && L.t[d][j] == L.t[d][bslot];
+        near = !same;
+    }
+    return near;
+}
+
+template <int D, bool TIES = false>
+ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
     double b = __builtin_inf();
     int bs = 0, bo = 0x7fffffff, zslot = 0;
     for (int j = 0; j < P.m; j++) {
@@ -77,6 +91,7 @@ ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const Grid
         }
         const int o = P.tperm[j];
         zslot = o == 0 ? j : zslot;
+        if (TIES) *tie = *tie || slot_tie<D>(bo != 0x7fffffff, acc, j, b, bs, L);
         const bool better = acc < b || (acc == b && acc < __builtin_inf() && o < bo);
         b = better ? acc : b;
         bs = better ? j : bs;
@@ -88,9 +103,9 @@ ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const Grid
 }
 
 // exact (d2, cloud index) update with the target in slot j
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void grid_eval(const double (&q)[D], const bool act, const int j, const LdsView<D>& L, const GridView& P,
-                        double& best, int& bslot) {
+                        double& best, int& bslot, bool* tie = nullptr) {
     double df = L.t[0][j] - q[0];
     double acc = df * df;
 #pragma unroll
@@ -98,10 +113,11 @@ ICPX_DEV void grid_eval(const double (&q)[D], const bool act, const int j, const
         df = L.t[d][j] - q[d];
         acc = acc + df * df;
     }
+    if (TIES) *tie = *tie || slot_tie<D>(act, acc, j, best, bslot, L);
     bool better = act && acc < best;
-    const bool tie = act && acc == best && j != bslot && bslot >= 0;
-    if (__any(tie)) {
-        if (tie) better = P.tperm[j] < P.tperm[bslot];
+    const bool eq = act && acc == best && j != bslot && bslot >= 0;
+    if (__any(eq)) {
+        if (eq) better = P.tperm[j] < P.tperm[bslot];
     }
     best = better ? acc : best;
     bslot = better ? j : bslot;
@@ -111,9 +127,9 @@ ICPX_DEV void grid_eval(const double (&q)[D], const bool act, const int j, const
 // neighbours in the sorted order (x runs fastest in the cell id), so a row is ONE run of slots;
 // two targets per step.  (best, bslot): running lexicographic minimum of (d2, cloud index);
 // bslot < 0 = none yet.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void grid_walk(const double (&q)[D], bool act, const int (&c0)[D], const int (&c1)[D], const LdsView<D>& L,
-                        const GridView& P, double& best, int& bslot) {
+                        const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
     const int G = P.g.G;
     int cy = c0[1], cz = D == 3 ? c0[D - 1] : 0;
     int j = 0, e = 0;
@@ -155,8 +171,8 @@ ICPX_DEV void grid_walk(const double (&q)[D], bool act, const int (&c0)[D], cons
             st_issued += 128;
 #endif
             const int ja = go ? j : 0, jb = two ? j + 1 : ja;
-            grid_eval<D>(q, go, ja, L, P, best, bslot);
-            grid_eval<D>(q, two, jb, L, P, best, bslot);
+            grid_eval<D, TIES>(q, go, ja, L, P, best, bslot, tie);
+            grid_eval<D, TIES>(q, two, jb, L, P, best, bslot, tie);
             j += two ? 2 : (go ? 1 : 0);
         }
     }
@@ -178,7 +194,9 @@ ICPX_DEV void grid_range(const double (&q)[D], double bound, const PairGrid& g, 
     // (the sum only adds non-negative terms and rounding is monotone), hence |t - q| <= sqrt(bound) *
     // (1 + 2^-51) + 2^-537 (the second term: squares that underflow).  R' covers that: the correctly
     // rounded root is >= (1 - 2^-53) of the true one, times (1 + 2^-50), plus 1e-150
-    const double R = __builtin_sqrt(bound) * (1.0 + 1.0 / 1125899906842624.0) + 1e-150;
+    // (2^-48 instead of the 2^-50 that would do: the kd rule's tie partners, up to kKdNearUlps above the bound, are
+    // inside the box too)
+    const double R = __builtin_sqrt(bound) * (1.0 + 1.0 / 281474976710656.0) + 1e-150;
 #pragma unroll
     for (int d = 0; d < D; d++) {
         // q -/+ R' rounds by at most 2^-53 (|q| + R'): widen by 2^-51 of that
@@ -194,7 +212,7 @@ ICPX_DEV void grid_range(const double (&q)[D], double bound, const PairGrid& g, 
 // the clamp to [0, G - 1] is monotone.
 template <int D>
 ICPX_DEV void grid_range_cells(const double (&q)[D], double bound, const PairGrid& g, int (&c0)[D], int (&c1)[D]) {
-    const double R = __builtin_sqrt(bound) * (1.0 + 1.0 / 1125899906842624.0) + 1e-150;  // as in grid_range
+    const double R = __builtin_sqrt(bound) * (1.0 + 1.0 / 281474976710656.0) + 1e-150;  // as in grid_range
     const double gm = static_cast<double>(g.G - 1);
 #pragma unroll
     for (int d = 0; d < D; d++) {
@@ -218,16 +236,16 @@ ICPX_DEV bool seed_certified(double d2_seed, double hc) {
 
 // Nearest neighbour of one query per lane.  seeded: (best, bslot) = exact d2 and slot of some
 // target on entry.  Out: lexicographic minimum of (d2, cloud index) over all targets, as its slot.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded, const LdsView<D>& L,
-                           const GridView& P, double& best, int& bslot) {
+                           const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
     bool fin = P.g.bad == 0;
 #pragma unroll
     for (int d = 0; d < D; d++) fin = fin && (__builtin_fabs(q[d]) < 1e150);
     if (__any(v && !fin)) {
         double lb;
         int ls;
-        exact_scan_p<D>(q, L, P, lb, ls);
+        exact_scan_p<D, TIES>(q, L, P, lb, ls, tie);  // (every target, the seed among them)
         bool take = true;
         if (seeded) take = lb < best || (lb == best && P.tperm[ls] < P.tperm[bslot]);
         best = take ? lb : best;
@@ -248,7 +266,7 @@ ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded
             b0[d] = cq > 0 ? cq - 1 : 0;
             b1[d] = cq < P.g.G - 1 ? cq + 1 : P.g.G - 1;
         }
-        grid_walk<D>(q, v, b0, b1, L, P, best, bslot);
+        grid_walk<D, TIES>(q, v, b0, b1, L, P, best, bslot, tie);
         grid_range<D>(q, best, P.g, c0, c1);  // best = +inf (nothing found): every cell
         bool inside = true;
 #pragma unroll
@@ -257,7 +275,7 @@ ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded
     } else {
         grid_range<D>(q, best, P.g, c0, c1);
     }
-    if (__any(need)) grid_walk<D>(q, need, c0, c1, L, P, best, bslot);
+    if (__any(need)) grid_walk<D, TIES>(q, need, c0, c1, L, P, best, bslot, tie);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -296,7 +314,7 @@ constexpr int kCoopSteps = kCoopCap / 64;
 constexpr int kCoopBlock = ICPX_COOP_BLOCK;      // steps whose loads are issued together
 
 inline __host__ __device__ size_t coop_wave_bytes(int dim) {
-    return static_cast<size_t>(64) * 8 * dim + 64 * 8 + 64 * 4 + 64 * 4 + static_cast<size_t>(kCoopCap + 64) * 4;
+    return static_cast<size_t>(64) * 8 * dim + 64 * 8 + 64 * 4 + 64 * 4 + static_cast<size_t>(kCoopCap + 64) * 4 + 64 * 4;
 }
 
 template <int D>
@@ -306,6 +324,7 @@ struct CoopStage {
     unsigned* acci;             // [64] lowest slot at the minimum; (cloud index << 16 | slot) after a tie
     unsigned* accx;             // [64] highest slot at the minimum; 0xffffffff marks a tied query
     unsigned* list;             // [kCoopCap + 64] (query lane << 16 | target slot); the last 64: per-lane dump
+    unsigned* acct;             // [64] kd rule: non-zero = a non-coincident target within kKdNearUlps of the minimum
 };
 
 template <int D>
@@ -316,6 +335,7 @@ ICPX_DEV CoopStage<D> coop_carve(char* base) {  // base: this wave's staging are
     S.acci = reinterpret_cast<unsigned*>(base + 64 * 8 * D + 64 * 8);
     S.accx = S.acci + 64;
     S.list = S.accx + 64;
+    S.acct = S.list + kCoopCap + 64;
     return S;
 }
 
@@ -351,9 +371,12 @@ ICPX_DEV int wave_incl_scan(int v) {
 // into the list, the whole wave evaluates it.  rs / rl: first slot and length of the box's rows (rl = 0 for the
 // rows a lane does not have); nrows: rows any lane of the wave has.  Out, for the lanes of grp: (rb, rsl) = the
 // box's lexicographic minimum of (d2, cloud index) and its slot, (+inf, -1) for an empty box.
-template <int D, int NR>
+// TIES (icpx_kd.h): the candidates within kKdNearUlps of the minimum report their slots too (instead of those AT the
+// minimum only), so `tied` also covers the kd rule's near ties; *tie |= the query has such a candidate that does not
+// coincide with the others.  The (d2, cloud index) answer is unchanged.
+template <int D, int NR, bool TIES = false>
 ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR], const int (&rl)[NR], const int nrows,
-                        const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl) {
+                        const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl, bool* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     ICPX_CYC_BEGIN();
 #pragma unroll
@@ -361,6 +384,7 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
     S.accd[lane] = 0x7ff0000000000000ull;  // +inf
     S.acci[lane] = 0xffffffffu;
     S.accx[lane] = 0u;
+    if (TIES) S.acct[lane] = 0u;
     // ---- the flat list, query-major: a lane's candidates follow those of the lanes before it ----
     int total = 0;
 #pragma unroll
@@ -466,7 +490,8 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
 #pragma unroll
             for (int u = 0; u < kCoopBlock; u++) {
                 const unsigned ql = ent[cb + u] >> 16, j = ent[cb + u] & 0xffffu;
-                const bool win = dk[cb + u] != ~0ull && dk[cb + u] == mn[u];
+                const bool win = dk[cb + u] != ~0ull && (TIES ? (dk[cb + u] - mn[u] <= kKdNearUlps && dk[cb + u] < 0x7ff0000000000000ull)
+                                                                 : dk[cb + u] == mn[u]);
 #if ICPX_RESOLVE_MASKED
                 if (win) {
                     __hip_atomic_fetch_min(&S.acci[ql], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -485,6 +510,24 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
     const bool mine = grp && total > 0;
     const bool tied = mine && S.acci[lane] != S.accx[lane];
     if (__any(tied)) {
+        if (TIES) {
+            // kd rule: does any candidate in the tie range differ in coordinates from the lowest such slot?
+#pragma unroll
+            for (int c = 0; c < kCoopSteps; c++) {
+                if (c * 64 < base) {
+                    const unsigned ql = ent[c] >> 16, j = ent[c] & 0xffffu;
+                    const unsigned lo_slot = S.acci[ql], hi_slot = S.accx[ql];
+                    if (dk[c] != ~0ull && dk[c] < 0x7ff0000000000000ull && dk[c] - S.accd[ql] <= kKdNearUlps && lo_slot != hi_slot && j != lo_slot) {
+                        bool same = true;
+#pragma unroll
+                        for (int d = 0; d < D; d++) same = same && L.t[d][j] == L.t[d][lo_slot];
+                        if (!same) S.acct[ql] = 1u;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         // exact ties between different targets: the candidates at the minimum compete by cloud index
         if (tied) {
             S.acci[lane] = 0xffffffffu;
@@ -510,6 +553,7 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
         if (total > 0) {
             rb = __longlong_as_double(static_cast<long long>(S.accd[lane]));
             rsl = static_cast<int>(S.acci[lane] & 0xffffu);
+            if (TIES) *tie = *tie || S.acct[lane] != 0u;
         } else {
             rb = __builtin_inf();
             rsl = -1;
@@ -521,9 +565,9 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
 // Lexicographic minimum of (d2, cloud index) over the targets of the cell box [c0, c1] of every lane with `act`
 // whose box has at most 3 x 3 rows: (rb, rsl), (+inf, -1) for an empty box.  Returns (per lane) whether the
 // lane's box was taken; the others (`big`) are the caller's business.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV bool coop_box(const double (&q)[D], const bool act, const int (&c0)[D], const int (&c1)[D],
-                       const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl) {
+                       const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl, bool* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     const int G = P.g.G;
     constexpr int NR = D == 3 ? 9 : 3;
@@ -577,7 +621,7 @@ ICPX_DEV bool coop_box(const double (&q)[D], const bool act, const int (&c0)[D],
     if (gmax > kCoopCap) return false;  // one query with more candidates than the list holds: nobody was taken
     for (int g = 0; g < 64; g += 1 << shift) {
         const bool grp = mine && (lane >> shift) == (g >> shift);
-        coop_pass<D, NR>(q, grp, rs, rl, nrows, L, P, S, rb, rsl);
+        coop_pass<D, NR, TIES>(q, grp, rs, rl, nrows, L, P, S, rb, rsl, tie);
     }
     return mine;
 }
@@ -589,9 +633,9 @@ ICPX_DEV bool coop_box(const double (&q)[D], const bool act, const int (&c0)[D],
 // slots from the box's first cell to its last (cells are in x-fastest order): a superset of the box's targets,
 // which is as good (everything at most as far as the bound is inside the box, hence inside the run).
 // (best, bslot) of the lanes in `walk`: running lexicographic minimum of (d2, cloud index), bslot < 0 = none yet.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w0)[D], const int (&w1)[D],
-                            const LdsView<D>& L, const GridView& P, double& best, int& bslot) {
+                            const LdsView<D>& L, const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     const int G = P.g.G;
     int first = 0, last = 0;
@@ -610,6 +654,7 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
         const int kb = P.cstart[__shfl(first, src)], ke = P.cstart[__shfl(last, src) + 1];
         double mb = __builtin_inf();
         int ms = -1;
+        bool lt = false;
         for (int j = kb + lane; j < ke; j += 64) {
             double df = L.t[0][j] - qq[0];
             double acc = df * df;
@@ -618,6 +663,7 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
                 df = L.t[d][j] - qq[d];
                 acc = acc + df * df;
             }
+            if (TIES) lt = lt || slot_tie<D>(true, acc, j, mb, ms, L);
             bool better = acc < mb;
             if (acc == mb && ms >= 0) better = P.tperm[j] < P.tperm[ms];
             mb = better ? acc : mb;
@@ -628,6 +674,7 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
         for (int o = 32; o >= 1; o >>= 1) {
             const double ob = __shfl_xor(mb, o);
             const int os = __shfl_xor(ms, o);
+            if (TIES) lt = lt || slot_tie<D>(os >= 0, ob, os, mb, ms, L);
             bool take = os >= 0 && (ms < 0 || ob < mb);
             const bool tie = os >= 0 && ms >= 0 && ob == mb && os != ms;
             if (__any(tie)) {
@@ -636,7 +683,9 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
             mb = take ? ob : mb;
             ms = take ? os : ms;
         }
+        if (TIES) lt = __any(lt);
         if (lane == src && ms >= 0) {
+            if (TIES) *tie = *tie || lt || slot_tie<D>(true, mb, ms, best, bslot, L);
             bool take = bslot < 0 || mb < best;
             if (bslot >= 0 && mb == best && ms != bslot) take = P.tperm[ms] < P.tperm[bslot];
             best = take ? mb : best;
@@ -658,14 +707,16 @@ ICPX_DEV bool box_inside(const int (&a0)[D], const int (&a1)[D], const int (&b0)
 // stage 0 found nothing or left a box too large for the list), 2: the box of its bound (complete: that box holds
 // every target at most that far, the bound's own target included) — one cooperative pass per trip, lanes in
 // different stages side by side.  A seeded lane whose bound gives a small box starts at stage 2: one trip.
-template <int D>
+// TIES: *tie |= a non-coincident target lies within kKdNearUlps of the answer (icpx_kd.h).  The pass that settles a
+// query evaluates every target that close (its box is that of the bound), so it also sees the tie partners.
+template <int D, bool TIES = false>
 ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded, const LdsView<D>& L,
-                           const GridView& P, const CoopStage<D>& S, double& best, int& bslot) {
+                           const GridView& P, const CoopStage<D>& S, double& best, int& bslot, bool* tie = nullptr) {
     bool fin = P.g.bad == 0;
 #pragma unroll
     for (int d = 0; d < D; d++) fin = fin && (__builtin_fabs(q[d]) < 1e150);
     if (__any(v && !fin)) {  // non-finite or huge coordinates in this wave: the per-lane path knows them
-        nn_grid_slot<D>(q, v, seeded, L, P, best, bslot);
+        nn_grid_slot<D, TIES>(q, v, seeded, L, P, best, bslot, tie);
         return;
     }
     const int G = P.g.G;
@@ -711,7 +762,7 @@ ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded
         const bool act = stage < 3;
         double rb = __builtin_inf();
         int rsl = -1;
-        const bool taken = coop_box<D>(q, act, c0, c1, L, P, S, rb, rsl);
+        const bool taken = coop_box<D, TIES>(q, act, c0, c1, L, P, S, rb, rsl, tie);
         // boxes the list did not take (more than 3 x 3 rows, or an overfull list): the per-lane walk, final
         // stage only (the local blocks always fit), from the lane's own candidate
         const bool walk = act && !taken;
@@ -725,7 +776,7 @@ ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded
                 w1[d] = r1[d];
             }
             if (stage < 2) grid_range<D>(q, best, P.g, w0, w1);  // (a local block that overflowed the list)
-            coop_run_scan<D>(q, walk, w0, w1, L, P, best, bslot);
+            coop_run_scan<D, TIES>(q, walk, w0, w1, L, P, best, bslot, tie);
             ICPX_CYC(24);  // the large boxes, one query at a time, the wave scanning together
         }
         if (act && taken) {
@@ -735,6 +786,7 @@ ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded
                 stage = 3;
             } else {
                 // a local block: its minimum joins the bound; ties go to the block (it is the lexicographic minimum there)
+                if (TIES) *tie = *tie || slot_tie<D>(rsl >= 0, rb, rsl, best, bslot, L);
                 const bool take = rsl >= 0 && !(rb > best);
                 best = take ? rb : best;
                 bslot = take ? rsl : bslot;

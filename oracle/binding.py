@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 VANILLA, TRIMMED, FEATURE_AWARE = 0, 1, 2
 FLAG_MATCH_TRANSFORMED, FLAG_FILL_MATCHES, FLAG_APPLY_GUESS = 1, 2, 4
-NN_KDTREE, NN_BRUTE = 0, 1
+NN_KDTREE, NN_BRUTE, NN_KDCANON = 0, 1, 2
 SUM_SEQUENTIAL, SUM_TREE64 = 0, 1
 
 HAS_MIN_ITER, HAS_MAX_ITER, HAS_STOP_COST, HAS_REL_TOL = 1, 2, 4, 8
@@ -69,6 +69,7 @@ def lib():
         L = C.CDLL(path)
         L.orc_nn_brute.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp]
         L.orc_nn_kdtree.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp]
+        L.orc_nn_kdcanon.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp, C.c_int, C.POINTER(C.c_int32)]
         L.orc_jacobi_svd.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.orc_kabsch.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.orc_sum.argtypes = [_dp, C.c_int64, C.c_int]
@@ -138,6 +139,18 @@ def nn_kdtree(q, t):
     dist = np.zeros(len(q), np.float64)
     lib().orc_nn_kdtree(dim, _d(q), len(q), _d(t), len(t), _i(idx), _d(dist))
     return idx, dist
+
+
+def nn_kdcanon(q, t, by_key=False, want_nodes=False):
+    """The kd-tree rule in canonical form (ORC_NN_KDCANON); dist is Euclidean."""
+    dim = q.shape[1]
+    q, t = _cloud(q, dim), _cloud(t, dim)
+    idx = np.zeros(len(q), np.int64)
+    dist = np.zeros(len(q), np.float64)
+    nodes = np.zeros(max(len(t), 1), np.int32)
+    lib().orc_nn_kdcanon(dim, _d(q), len(q), _d(t), len(t), _i(idx), _d(dist), 1 if by_key else 0,
+                         nodes.ctypes.data_as(C.POINTER(C.c_int32)))
+    return (idx, dist, nodes[:len(t)]) if want_nodes else (idx, dist)
 
 
 def ref_nn_kdtree(q, t):

@@ -182,6 +182,167 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------
+// The kd-tree RULE, canonical form (ORC_NN_KDCANON) — what the HIP kernels are held to for the
+// kd-tree-backed methods (vanilla 2D, both 3D).
+//
+// kdtree.h:132-154 compares sqrt(d2) with strict < and keeps the first node it visits, children
+// near side first.  Pruning never hides that node, so the reference's answer is
+//   among the targets whose sqrt(d2) equals the minimal sqrt(d2), bit for bit, the one that comes
+//   FIRST in the near-child-first pre-order of the tree for this query.
+// The tree (kdtree.h:96-116) is the median-split tree, median = element (n - 1) / 2 of the subset
+// ordered by the split coordinate.  With distinct coordinates that tree is unique; where a subset
+// holds equal coordinates std::nth_element's pick is implementation-defined, and this canonical
+// form orders (coordinate, index) — still a tree the reference could have built.  Coincident targets
+// (all coordinates equal) are indistinguishable to the reference's callers except by index, whose
+// choice among them is again nth_element's: the canonical answer is the LOWEST index among the
+// targets coincident with the first-visited one.
+// Two formulations, cross-checked by tests/test_oracle.py: search() walks the tree like the
+// reference; search_by_key() takes the brute-force minimum, collects the tied set and compares
+// pre-order keys (the formulation of the kernels' tie resolution, icp_amd/csrc/icpx_kd.h).
+// ---------------------------------------------------------------------------------------------
+inline uint64_t ord_key(double v) {  // order-preserving f64 -> u64 (a total order, NaN included)
+    uint64_t b;
+    std::memcpy(&b, &v, sizeof(b));
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+
+template <int D>
+class KdCanon {
+public:
+    void build(const double* pts, int64_t m) {
+        pts_ = pts;
+        m_ = static_cast<int>(m);
+        node_.resize(static_cast<size_t>(m));
+        std::iota(node_.begin(), node_.end(), 0);
+        build_range(0, m_, 0);
+        pos_.assign(static_cast<size_t>(m), 0);
+        for (int p = 0; p < m_; p++) pos_[node_[p]] = p;
+        // lowest index among coincident targets (-0.0 == +0.0; NaN coincides with nothing)
+        std::vector<int> order(static_cast<size_t>(m));
+        std::iota(order.begin(), order.end(), 0);
+        auto nk = [this](int i, int d) { double v = pts_[static_cast<int64_t>(i) * D + d]; return ord_key(v == 0.0 ? 0.0 : v); };
+        std::sort(order.begin(), order.end(), [&](int x, int y) {
+            for (int d = 0; d < D; d++) {
+                uint64_t kx = nk(x, d), ky = nk(y, d);
+                if (kx != ky) return kx < ky;
+            }
+            return x < y;
+        });
+        dupmin_.assign(static_cast<size_t>(m), 0);
+        for (int r = 0; r < m_; r++) {
+            int i = order[r];
+            bool same = r > 0;
+            if (same) {
+                int j = order[r - 1];
+                for (int d = 0; d < D; d++) same = same && pts_[static_cast<int64_t>(i) * D + d] == pts_[static_cast<int64_t>(j) * D + d];
+            }
+            dupmin_[i] = same ? dupmin_[order[r - 1]] : i;
+        }
+    }
+
+    // tree walk of the reference (kdtree.h:132-154) on the canonical tree; dist is Euclidean
+    int search(const double* q, double* dist) const {
+        int guess = -1;
+        double md = std::numeric_limits<double>::max();
+        walk(q, 0, m_, 0, &guess, &md);
+        if (guess < 0) {  // nothing at a finite distance: the (d2, index) rule's convention
+            *dist = std::numeric_limits<double>::infinity();
+            return 0;
+        }
+        *dist = md;
+        return dupmin_[guess];
+    }
+
+    // pre-order key of target t for query q: 2 bits per level from the root, 0 = this node, 1 = near child, 2 = far
+    uint64_t key(const double* q, int t) const {
+        const int P = pos_[t];
+        int lo = 0, hi = m_;
+        uint64_t k = 0;
+        for (int depth = 0; depth < 31; depth++) {
+            const int mid = lo + (hi - lo - 1) / 2;
+            if (P == mid) break;
+            const int axis = depth % D;
+            const bool near_left = q[axis] < pts_[static_cast<int64_t>(node_[mid]) * D + axis];  // kdtree.h:146
+            const bool go_left = P < mid;
+            k |= static_cast<uint64_t>(go_left == near_left ? 1 : 2) << (60 - 2 * depth);
+            if (go_left) hi = mid;
+            else lo = mid + 1;
+        }
+        return k;
+    }
+
+    // the same answer without walking: brute-force minimum, tied set, smallest key
+    int search_by_key(const double* q, double* dist) const {
+        double best = std::numeric_limits<double>::infinity();
+        for (int j = 0; j < m_; j++) {
+            double d = sqdist<D>(pts_ + static_cast<int64_t>(j) * D, q);
+            if (d < best) best = d;
+        }
+        if (!(best < std::numeric_limits<double>::infinity())) {
+            *dist = std::numeric_limits<double>::infinity();
+            return 0;
+        }
+        const double s = std::sqrt(best);
+        int win = -1;
+        uint64_t wk = 0;
+        for (int j = 0; j < m_; j++) {
+            double d = sqdist<D>(pts_ + static_cast<int64_t>(j) * D, q);
+            if (std::sqrt(d) == s) {
+                uint64_t k = key(q, j);
+                if (win < 0 || k < wk) {
+                    win = j;
+                    wk = k;
+                }
+            }
+        }
+        *dist = s;
+        return dupmin_[win];
+    }
+
+    const std::vector<int>& nodes() const { return node_; }
+
+private:
+    void build_range(int lo, int hi, int depth) {
+        if (hi - lo <= 0) return;
+        const int axis = depth % D;
+        const int mid = lo + (hi - lo - 1) / 2;
+        const double* p = pts_;
+        std::nth_element(node_.begin() + lo, node_.begin() + mid, node_.begin() + hi, [p, axis](int x, int y) {
+            uint64_t kx = ord_key(p[static_cast<int64_t>(x) * D + axis]), ky = ord_key(p[static_cast<int64_t>(y) * D + axis]);
+            return kx < ky || (kx == ky && x < y);
+        });
+        build_range(lo, mid, depth + 1);
+        build_range(mid + 1, hi, depth + 1);
+    }
+
+    void walk(const double* q, int lo, int hi, int depth, int* guess, double* md) const {
+        if (hi - lo <= 0) return;
+        const int mid = lo + (hi - lo - 1) / 2;
+        const double* train = pts_ + static_cast<int64_t>(node_[mid]) * D;
+        double dist = 0;
+        for (int i = 0; i < D; i++) dist += (q[i] - train[i]) * (q[i] - train[i]);
+        dist = std::sqrt(dist);
+        if (dist < *md) {
+            *md = dist;
+            *guess = node_[mid];
+        }
+        const int axis = depth % D;
+        const bool left_first = q[axis] < train[axis];
+        if (left_first) walk(q, lo, mid, depth + 1, guess, md);
+        else walk(q, mid + 1, hi, depth + 1, guess, md);
+        const double diff = std::fabs(q[axis] - train[axis]);
+        if (diff < *md) {
+            if (left_first) walk(q, mid + 1, hi, depth + 1, guess, md);
+            else walk(q, lo, mid, depth + 1, guess, md);
+        }
+    }
+
+    const double* pts_ = nullptr;
+    int m_ = 0;
+    std::vector<int> node_, pos_, dupmin_;
+};
+
+// ---------------------------------------------------------------------------------------------
 // small dense algebra (column-major, D x D) restating the Eigen 3.4 routines the reference calls
 // ---------------------------------------------------------------------------------------------
 
@@ -477,6 +638,8 @@ struct Icp : IcpBase {
     std::vector<Match> matches;
     std::vector<double> cur;  // a_current (2D) / c (3D)
     KdTree<D> kdtree;         // 3D: built once in setup (vanilla_3d.cpp:75-80)
+    KdCanon<D> kdcanon;       // ORC_NN_KDCANON: the same rule in canonical form (device order)
+    bool canon_by_key = false;  // non-finite input: the brute-force formulation (no pruning to reason about)
     std::vector<int64_t> nb_idx;
     std::vector<double> nb_dist;
     std::vector<double> nfd;  // FeatureAware: normalized_feature_dists, n x m row-major (feature_aware.h:60)
@@ -513,6 +676,15 @@ struct Icp : IcpBase {
             std::vector<double> d2(static_cast<size_t>(n));
             nn_brute<D>(q.data(), n, b.data(), m, idx.data(), d2.data());
             for (int64_t i = 0; i < n; i++) dist[i] = std::sqrt(d2[i]);
+        } else if (prm.nn_mode == ORC_NN_KDCANON) {
+            if (rebuild) build_canon();
+            bool by_key = canon_by_key;
+            for (size_t e = 0; e < q.size() && !by_key; e++) by_key = !std::isfinite(q[e]);
+            for (int64_t i = 0; i < n; i++) {
+                double md = 0.0;
+                idx[i] = by_key ? kdcanon.search_by_key(&q[i * D], &md) : kdcanon.search(&q[i * D], &md);
+                dist[i] = md;
+            }
         } else {
             if (rebuild) kdtree.build(b.data(), m);
             for (int64_t i = 0; i < n; i++) {
@@ -521,6 +693,11 @@ struct Icp : IcpBase {
                 dist[i] = md;
             }
         }
+    }
+    void build_canon() {
+        kdcanon.build(b.data(), m);
+        canon_by_key = false;
+        for (double v : b) canon_by_key = canon_by_key || !std::isfinite(v);
     }
 
     // ---- FeatureAware (lib/icp/impl/feature_aware.cpp), ICP2 only ----
@@ -617,6 +794,7 @@ struct Icp : IcpBase {
             cur = a;
             if (prm.flags & ORC_FLAG_APPLY_GUESS) apply_transform_to(a, cur, transform);  // opt-in, fixes Q5
             if (prm.nn_mode == ORC_NN_KDTREE) kdtree.build(b.data(), m);
+            if (prm.nn_mode == ORC_NN_KDCANON) build_canon();
             if ((prm.flags & ORC_FLAG_FILL_MATCHES) && n > 0 && m > 0) {  // opt-in, fixes Q4
                 nn_tree_or_brute(cur, false, nb_idx, nb_dist);
                 for (int64_t i = 0; i < n; i++) {
@@ -944,6 +1122,13 @@ void converge(IcpBase* icp, const double* src, int64_t n, const double* dst, int
     *out = state;
 }
 
+template <int D>
+void nn_kdcanon(const double* q, int64_t n, const double* t, int64_t m, int64_t* idx, double* dist, int by_key, int32_t* nodes) {
+    KdCanon<D> kt;
+    kt.build(t, m);
+    for (int64_t i = 0; i < n; i++) idx[i] = by_key ? kt.search_by_key(q + i * D, dist + i) : kt.search(q + i * D, dist + i);
+    if (nodes) std::memcpy(nodes, kt.nodes().data(), sizeof(int32_t) * static_cast<size_t>(m));
+}
 }  // namespace
 
 struct orc_icp {
@@ -969,6 +1154,19 @@ void orc_nn_kdtree(int dim, const double* q, int64_t n, const double* t, int64_t
         kt.build(t, m);
         for (int64_t i = 0; i < n; i++) idx[i] = kt.search(q + i * 3, dist + i);
     }
+}
+
+void orc_nn_kdcanon(int dim, const double* q, int64_t n, const double* t, int64_t m, int64_t* idx,
+                    double* dist, int by_key, int32_t* nodes) {
+    if (m <= 0) {
+        for (int64_t i = 0; i < n; i++) {
+            idx[i] = 0;
+            dist[i] = std::numeric_limits<double>::infinity();
+        }
+        return;
+    }
+    if (dim == 2) nn_kdcanon<2>(q, n, t, m, idx, dist, by_key, nodes);
+    else nn_kdcanon<3>(q, n, t, m, idx, dist, by_key, nodes);
 }
 
 void orc_jacobi_svd(int dim, const double* a, double* u, double* s, double* v) {

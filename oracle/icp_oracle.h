@@ -39,7 +39,11 @@ enum { ORC_VANILLA = 0, ORC_TRIMMED = 1, ORC_FEATURE_AWARE = 2 /* ICP2 only */ }
 /* how correspondences are found for the kd-tree methods (vanilla 2D, both 3D) */
 enum {
     ORC_NN_KDTREE = 0, /* restated reference kd-tree: first-visited wins ties (kdtree.h:132-154) */
-    ORC_NN_BRUTE = 1   /* canonical rule: lexicographic min of (d2, target index)               */
+    ORC_NN_BRUTE = 1,  /* brute-force rule: lexicographic min of (d2, target index)             */
+    ORC_NN_KDCANON = 2 /* the kd-tree's rule in canonical form (icp_oracle.cpp, KdCanon): first-visited among the
+                          minimal sqrt(d2), tree ordered by (coordinate, index), lowest index among coincident
+                          targets.  Equals ORC_NN_KDTREE wherever split coordinates are distinct; the rule the
+                          HIP kernels implement for vanilla 2D and both 3D methods */
 };
 
 /* floating-point summation order of the centroid / covariance / cost reductions */
@@ -106,6 +110,12 @@ void orc_nn_brute(int dim, const double* q, int64_t n, const double* t, int64_t 
 /* kdtree.h:42-52,79-89,96-154 restated; dist is Euclidean (sqrt), as kdtree.h:126 */
 void orc_nn_kdtree(int dim, const double* q, int64_t n, const double* t, int64_t m, int64_t* idx,
                    double* dist);
+
+/* ORC_NN_KDCANON stand-alone.  by_key != 0: the brute-force formulation (minimum, tied set, smallest pre-order
+ * key) instead of the tree walk — same answers, cross-checked in tests.  nodes (may be NULL): the canonical
+ * tree in in-order layout, m entries (node of the range [lo, hi) sits at lo + (hi - lo - 1) / 2) */
+void orc_nn_kdcanon(int dim, const double* q, int64_t n, const double* t, int64_t m, int64_t* idx,
+                    double* dist, int by_key, int32_t* nodes);
 
 /* Eigen 3.4 JacobiSVD (FullU|FullV) for dim x dim, column-major in/out */
 void orc_jacobi_svd(int dim, const double* a, double* u, double* s, double* v);

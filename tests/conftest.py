@@ -183,3 +183,62 @@ def check_case_3d(T, iters, case):
     if max_it is not None:
         assert iters <= max_it, name
 
+
+
+def tie_clouds(dim, n_random, m_random, planted, seed):
+    """(queries, targets, planted query indices) with PLANTED kd-rule ties and, with overwhelming probability,
+    pairwise distinct coordinates on every axis — the data on which the reference's kd-tree is uniquely defined
+    and its first-visited pick differs from the (d2, index) rule about half of the time.  Two families per
+    planted query q (nothing else is nearer than its partners):
+      exact   two targets at q + v and q + v' with v' a signed permutation of v on a 2^-20 lattice: all the
+              arithmetic is exact, so the two d2 are bit-equal;
+      sqrt    two targets whose d2 differ by a few ulps and round to ONE square root (found by trial):
+              the case of ex_data/scan1, source 109."""
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-10, 10, (n_random, dim))
+    t = rng.uniform(-10, 10, (m_random, dim))
+    lat = 2.0 ** -20
+    pq, pt = [], []
+    for k in range(planted):
+        c = np.round(rng.uniform(-9, 9, dim) / lat) * lat
+        r = 1e-3 * (1 + rng.random())
+        if k % 2 == 0:
+            while True:
+                v = np.round(rng.normal(size=dim) / lat * r) * lat
+                v2 = v[rng.permutation(dim)] * rng.choice([-1.0, 1.0], dim)
+                if np.all(v2 != v) and np.all(v != 0):
+                    break
+            pq.append(c)
+            pt += [c + v, c + v2]
+        else:
+            for _ in range(2000):
+                v = rng.normal(size=dim)
+                v *= r / np.linalg.norm(v)
+                w = rng.normal(size=dim)
+                w *= r / np.linalg.norm(w)
+                # nudge w's length until the two squared distances are a few ulps apart with one square root
+                t1, t2 = c + v, c + w
+                d1 = (((t1 - c) ** 2).cumsum())[-1]
+                for _ in range(60):
+                    d2 = (((t2 - c) ** 2).cumsum())[-1]
+                    if d2 == d1 or np.sqrt(d2) == np.sqrt(d1):
+                        break
+                    t2 = c + (t2 - c) * np.sqrt(d1 / d2)
+                d2 = (((t2 - c) ** 2).cumsum())[-1]
+                if d2 != d1 and np.sqrt(d2) == np.sqrt(d1):
+                    break
+            pq.append(c)
+            pt += [t1, t2]
+    pq, pt = np.array(pq).reshape(-1, dim), np.array(pt).reshape(-1, dim)
+    # keep random targets away from the planted queries
+    if len(pq):
+        far = np.ones(len(t), bool)
+        for c in pq:
+            far &= ((t - c) ** 2).sum(axis=1) > (0.05) ** 2
+        t = t[far]
+    order_t = rng.permutation(len(t) + len(pt))
+    order_q = rng.permutation(len(q) + len(pq))
+    tt = np.concatenate([t, pt])[order_t]
+    qq = np.concatenate([q, pq])[order_q]
+    planted_idx = np.nonzero(order_q >= len(q))[0]
+    return np.ascontiguousarray(qq), np.ascontiguousarray(tt), planted_idx

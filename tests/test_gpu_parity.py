@@ -27,7 +27,7 @@ def icp():
 
 
 def dev_oracle(ob, dim, method, **kw):
-    return ob.OracleICP(dim, method, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64, **kw)
+    return ob.OracleICP(dim, method, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64, **kw)
 
 
 def driver(icp, cls, method, crit, config=None, **kw):

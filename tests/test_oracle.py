@@ -131,7 +131,7 @@ def test_tree64_sum_matches_sequential_closely(ob):
 @pytest.mark.parametrize("method,overlap", [("vanilla", 0.9), ("trimmed", 1.0)])
 @pytest.mark.parametrize("modes", ["ref", "dev"])
 def test_reference_2d_cases_on_oracle(ob, method, overlap, modes):
-    nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if modes == "ref" else (ob.NN_BRUTE, ob.SUM_TREE64)
+    nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if modes == "ref" else (ob.NN_KDCANON, ob.SUM_TREE64)
     for case in reference_cases_2d():
         o = ob.OracleICP(2, method, overlap_rate=overlap, nn_mode=nn, sum_mode=sm)
         r = o.converge(case[1], case[2], None, ob.make_criteria(**TEST_CRIT))
@@ -184,7 +184,7 @@ def test_feature_aware_features_against_numpy(ob, scans):
 
 @pytest.mark.parametrize("modes", ["ref", "dev"])
 def test_reference_3d_cases_on_oracle(ob, modes):
-    nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if modes == "ref" else (ob.NN_BRUTE, ob.SUM_TREE64)
+    nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if modes == "ref" else (ob.NN_KDCANON, ob.SUM_TREE64)
     for case in reference_cases_3d():
         o = ob.OracleICP(3, "vanilla", nn_mode=nn, sum_mode=sm)
         r = o.converge(case[1], case[2], None, ob.make_criteria(**TEST_CRIT))
@@ -195,7 +195,7 @@ def test_golden_traces_reproduce(ob, scans, queen, traces):
     """The committed traces (tests/tools/make_golden.py) pin the oracle; SURVEY §8c sanity anchors too."""
     for key, g in traces.items():
         data, method, mode = key.split("/")
-        nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if mode == "ref" else (ob.NN_BRUTE, ob.SUM_TREE64)
+        nn, sm = (ob.NN_KDTREE, ob.SUM_SEQUENTIAL) if mode == "ref" else (ob.NN_KDCANON, ob.SUM_TREE64)
         if data == "queen":
             src, dst = queen
             dim, crit = 3, PLY_CRIT

@@ -19,7 +19,7 @@ def verify_sample(ob, shard_obj, count_per_dim: int) -> int:
             continue
         for k in sample_pairs(st["it"].astype(np.int64), count_per_dim):
             a, b = shard_obj.host_pair(dim, k)
-            ro = ob.OracleICP(dim, method, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64).converge(a, b, None, ocrit)
+            ro = ob.OracleICP(dim, method, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64).converge(a, b, None, ocrit)
             assert int(st["it"][k]) == ro.iteration_count, (dim, k, int(st["it"][k]), ro.iteration_count)
             assert np.array_equal(transform_of(st[k], dim), ro.transform), (dim, k)
             assert st["cost"][k] == ro.cost, (dim, k)

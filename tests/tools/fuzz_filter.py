@@ -46,7 +46,7 @@ for rnd in range(rounds):
     icp_amd._lib.check(icp_amd._lib.load().icpx_debug_knob(b"ICPX_COOP", coop.encode()))
     cost, it, tr = icp_amd.converge_batch(dim, method, S, so, T, to, crit, config=cfg, device=0)
     for p in range(pairs):
-        o = ob.OracleICP(dim, method, overlap_rate=ov, max_distance=md, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64)
+        o = ob.OracleICP(dim, method, overlap_rate=ov, max_distance=md, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64)
         r = o.converge(S[so[p]:so[p + 1]], T[to[p]:to[p + 1]], None, ob.make_criteria(max_iterations=iters))
         same = np.array_equal(tr[p], r.transform, equal_nan=True) and it[p] == r.iteration_count and \
             (cost[p] == r.cost or (np.isnan(cost[p]) and np.isnan(r.cost)))

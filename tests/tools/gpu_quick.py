@@ -26,7 +26,7 @@ for method in ("vanilla", "trimmed"):
         drv = icp_amd.ICPDriver(icp)
         drv.set_max_iterations(50); drv.set_transform_tolerance(0.1 * np.pi / 180, 0.01)
         t = time.time(); r = drv.converge(a, b); dt = time.time() - t
-        o = ob.OracleICP(2, method, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64)
+        o = ob.OracleICP(2, method, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64)
         ro = o.converge(a, b, None, ob.make_criteria(**crit_kw))
         print(method, k, "iters", r.iteration_count, ro.iteration_count, "cost", r.cost, ro.cost,
               "T bitexact", np.array_equal(r.transform, ro.transform), "maxdiff", np.abs(r.transform - ro.transform).max(), f"{dt*1e3:.2f}ms", flush=True)
@@ -42,7 +42,7 @@ for method in ("vanilla", "trimmed"):
     icp = icp_amd.ICP3.from_method(method)
     drv = icp_amd.ICPDriver(icp); drv.set_max_iterations(100); drv.set_transform_tolerance(1e-4, 1e-4)
     t = time.time(); r = drv.converge(qt, q); dt = time.time() - t
-    o = ob.OracleICP(3, method, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64)
+    o = ob.OracleICP(3, method, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64)
     ro = o.converge(qt, q, None, ob.make_criteria(max_iterations=100, transform_tol=(1e-4, 1e-4)))
     print("queen", method, "iters", r.iteration_count, ro.iteration_count, "T bitexact", np.array_equal(r.transform, ro.transform),
           "maxdiff", np.abs(r.transform - ro.transform).max(), f"{dt*1e3:.2f}ms", flush=True)
@@ -56,7 +56,7 @@ for method in ("vanilla", "trimmed"):
     icp = icp_amd.ICP3.from_method(method)
     drv = icp_amd.ICPDriver(icp); drv.set_max_iterations(30); drv.set_transform_tolerance(1e-6, 1e-6)
     r = drv.converge(a3, b3)
-    o = ob.OracleICP(3, method, nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_TREE64)
+    o = ob.OracleICP(3, method, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64)
     ro = o.converge(a3, b3, None, ob.make_criteria(max_iterations=30, transform_tol=(1e-6, 1e-6)))
     print("fused3d", method, "iters", r.iteration_count, ro.iteration_count, "T bitexact", np.array_equal(r.transform, ro.transform),
           "maxdiff", np.abs(r.transform - ro.transform).max(), flush=True)

@@ -36,20 +36,20 @@ def run(dim, method, src, dst, crit_kw, nn_mode, sum_mode):
 
 def main():
     out = {"_doc": "hex floats; transforms row-major (dim+1)^2; modes: ref = kd-tree NN + "
-                   "sequential sums (reference order), dev = (d2,index) NN + TREE64 sums (device order)"}
+                   "sequential sums (reference order), dev = kd-tree rule in canonical form (ORC_NN_KDCANON; brute force for trimmed ICP2) + TREE64 sums (device order)"}
     bench = dict(max_iterations=50, transform_tol=(0.1 * np.pi / 180, 0.01))  # bench/bench.cpp:109-113
     for k in (1, 2, 3):
         a = iio.parse_lidar_scan(f"{G}/ex_data/scan{k}/first.csv")
         b = iio.parse_lidar_scan(f"{G}/ex_data/scan{k}/second.csv")
         for method in ("vanilla", "trimmed"):
             out[f"scan{k}/{method}/ref"] = run(2, method, a, b, bench, ob.NN_KDTREE, ob.SUM_SEQUENTIAL)
-            out[f"scan{k}/{method}/dev"] = run(2, method, a, b, bench, ob.NN_BRUTE, ob.SUM_TREE64)
+            out[f"scan{k}/{method}/dev"] = run(2, method, a, b, bench, ob.NN_KDCANON, ob.SUM_TREE64)
     q = iio.read_ply_vertices(f"{G}/ex_data/ply/queen.ply")
     qt = iio.read_ply_vertices(f"{G}/ex_data/ply/queen_transformed.ply")
     ply = dict(max_iterations=100, transform_tol=(1e-4, 1e-4))  # tests/test_ply.cpp:22-23,104-105
     for method in ("vanilla", "trimmed"):
         out[f"queen/{method}/ref"] = run(3, method, qt, q, ply, ob.NN_KDTREE, ob.SUM_SEQUENTIAL)
-        out[f"queen/{method}/dev"] = run(3, method, qt, q, ply, ob.NN_BRUTE, ob.SUM_TREE64)
+        out[f"queen/{method}/dev"] = run(3, method, qt, q, ply, ob.NN_KDCANON, ob.SUM_TREE64)
     with open(os.path.join(G, "traces.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote", os.path.join(G, "traces.json"))
