@@ -6,9 +6,9 @@ is its Python host side: the mirror of the reference's ICP / ICPDriver / Config 
 benchmarks use (synth.py).
 """
 from .api import (ICP2, ICP3, Config, ConvergenceState, ICPDriver, Match, converge_batch,
-                  make_criteria, nearest_neighbors)
+                  make_criteria, nearest_neighbors, nearest_neighbors_kdtree)
 from ._lib import IcpxError, NN_AUTO, NN_BRUTE, NN_GRID, NN_BVH, TRIMMED, VANILLA
 
 __all__ = ["ICP2", "ICP3", "Config", "ConvergenceState", "ICPDriver", "Match", "converge_batch",
-           "make_criteria", "nearest_neighbors", "IcpxError", "NN_AUTO", "NN_BRUTE", "NN_GRID", "NN_BVH",
+           "make_criteria", "nearest_neighbors", "nearest_neighbors_kdtree", "IcpxError", "NN_AUTO", "NN_BRUTE", "NN_GRID", "NN_BVH",
            "TRIMMED", "VANILLA"]

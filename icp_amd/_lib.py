@@ -49,7 +49,7 @@ SYMBOLS = [
     "icpx_destroy", "icpx_begin", "icpx_iterate", "icpx_cost", "icpx_transform", "icpx_matches",
     "icpx_sizes", "icpx_debug_neighbors", "icpx_converge", "icpx_converge_batch", "icpx_nn",
     "icpx_nn_grid_profile", "icpx_converge_batch_multi", "icpx_debug_knob",
-    "icpx_converge_batch_noalloc",
+    "icpx_converge_batch_noalloc", "icpx_nn_kdtree",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def _bind(path):
     if hasattr(L, "icpx_converge_batch_noalloc"):
         L.icpx_converge_batch_noalloc.argtypes = L.icpx_converge_batch.argtypes
     L.icpx_nn.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int, _vp]
+    L.icpx_nn_kdtree.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int, _vp]
     return L
 
 

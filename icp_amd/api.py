@@ -329,3 +329,18 @@ def nearest_neighbors(queries, targets, mode=L.NN_AUTO, device=-1, stream=None, 
     d2 = np.zeros(n, np.float64)
     L.check(lib.icpx_nn(dim, qp, n, tp, m, idx.ctypes.data, d2.ctypes.data, mode, device, stream))
     return idx, d2
+
+
+def nearest_neighbors_kdtree(queries, targets, mode=L.NN_AUTO, device=-1, stream=None):
+    """icpx_nn_kdtree: KdTree::search (kdtree.h:79-89) for every query — the target the reference's tree walk
+    returns and its Euclidean distance."""
+    lib = L.load()
+    if not hasattr(queries, "data_ptr"):
+        queries = np.ascontiguousarray(queries, np.float64)
+    dim = queries.shape[1]
+    qp, n, _q = _ptr_of(queries, dim, "queries")
+    tp, m, _t = _ptr_of(targets, dim, "targets")
+    idx = np.zeros(n, np.int64)
+    dist = np.zeros(n, np.float64)
+    L.check(lib.icpx_nn_kdtree(dim, qp, n, tp, m, idx.ctypes.data, dist.ctypes.data, mode, device, stream))
+    return idx, dist

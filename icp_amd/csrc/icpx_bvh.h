@@ -224,8 +224,10 @@ ICPX_DEV void bvh_stage_top(const BvhView& v, float* lds_top) {
 }
 
 // one query.  Returns (best d2, lowest index among equal d2); (inf, 0) when no target has a finite distance.
-template <int D>
-ICPX_DEV void bvh_query(const BvhView& v, const float* top, const double* q, double& best_out, int& idx_out, int& visited) {
+// TIES: as in icpx_grid.h (a node is skipped only when everything below it is farther than (1 + 2^-41) times the best)
+template <int D, bool TIES = false>
+ICPX_DEV void bvh_query(const BvhView& v, const float* top, const double* q, double& best_out, int& idx_out, int& visited,
+                        int& tie, const double* __restrict__ cloud) {
     double best = __builtin_inf();
     int bidx = 0x7fffffff;
     bool qfin = v.P > 0 && v.m > 0;
@@ -276,9 +278,8 @@ ICPX_DEV void bvh_query(const BvhView& v, const float* top, const double* q, dou
                             dist = dist + df * df;
                         }
                         const int j = static_cast<int>(rec[u].idx);
-                        const bool take = (k0 + u < ke) && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
-                        best = take ? dist : best;
-                        bidx = take ? j : bidx;
+                        const double cc[3] = {rec[u].x, rec[u].y, rec[u].z};
+                        nn_take<TIES, D>(k0 + u < ke, dist, j, cc, cloud, best, bidx, tie);
                     }
                 }
                 visited += ke > kb ? static_cast<int>(ke - kb) : 0;
@@ -290,10 +291,12 @@ ICPX_DEV void bvh_query(const BvhView& v, const float* top, const double* q, dou
     idx_out = bidx == 0x7fffffff ? 0 : bidx;
 }
 
-template <int D>
+template <int D, bool TIES = false>
 __global__ void __launch_bounds__(256)
 bvh_nn_kernel(const double* __restrict__ q, int64_t n, BvhView v, int64_t* __restrict__ idx, double* __restrict__ d2,
-              unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm) {
+              unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm,
+              const double* __restrict__ cloud = nullptr, uint32_t* __restrict__ kd_list = nullptr,
+              int* __restrict__ kd_count = nullptr) {
     __shared__ float top[kBvhTopNodes * 6];
     bvh_stage_top(v, top);
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -306,9 +309,11 @@ bvh_nn_kernel(const double* __restrict__ q, int64_t n, BvhView v, int64_t* __res
         for (int d = 0; d < D; d++) qq[d] = q[i * D + d];
         double best;
         int bi;
-        bvh_query<D>(v, top, qq, best, bi, visited);
+        int tie = 0;
+        bvh_query<D, TIES>(v, top, qq, best, bi, visited, tie, cloud);
         if (idx) idx[i] = bi;
         if (d2) d2[i] = best;
+        if (TIES && tie) kd_list[atomicAdd(kd_count, 1)] = static_cast<uint32_t>(i);
     }
     if (visited_total) {
         int s = wave_sum_int(visited);

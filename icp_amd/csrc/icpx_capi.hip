@@ -325,6 +325,7 @@ struct Workspace {
     DevBuf src, dst, soff, doff, guesses, states, out, part_d2, part_idx, q, t, idx, d2, sched, cur, seeds;
     DevBuf tperm, grids, cstart, hcert;  // grid-pruned search of the batch entry point
     DevBuf kd, kd_words;                 // kd rule: trees of the target clouds; one counter (16 bytes) per fused run
+    DevBuf kd_list;                      // kd rule of the stand-alone query: counter (16 bytes) + flagged queries
     GridIndex* grid = nullptr;    // grow-only uniform-grid index of the stand-alone queries
     BvhIndex* bvh = nullptr;      // likewise, ICPX_NN_BVH
     // pinned staging of the offset arrays, so that a stream-ordered call can return before they are consumed
@@ -1379,8 +1380,9 @@ int icpx_debug_knob(const char* name, const char* value) {
     });
 }
 
-int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
-            int64_t* idx, double* d2, int mode, int device, void* stream_) {
+// icpx_nn (kd = false) and icpx_nn_kdtree (kd = true: the kd-tree's tie rule, `d2` receives Euclidean distances)
+static int nn_impl(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+                   int64_t* idx, double* d2, int mode, int device, void* stream_, const bool kd) {
     return guarded([&]() -> int {
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
     if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "negative cloud size");
@@ -1421,6 +1423,20 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
         ICPX_TRY(ws.d2.reserve(sizeof(double) * n));
         d_d2 = ws.d2.as<double>();
     }
+    // kd rule (icpx_kd.h): the searches flag the queries that have a tie partner; they are resolved afterwards
+    KdTies ties;
+    if (kd && m > 0) {
+        if (!d_idx) {  // the resolution corrects indices: it needs them even when the caller does not
+            ICPX_TRY(ws.idx.reserve(sizeof(int64_t) * n));
+            d_idx = ws.idx.as<int64_t>();
+        }
+        ICPX_TRY(ws.kd_list.reserve(sizeof(uint32_t) * n + 16));
+        ties.cloud = d_t;
+        ties.count = ws.kd_list.as<int>();
+        ties.list = ws.kd_list.as<uint32_t>() + 4;
+        ICPX_HIP(hipMemsetAsync(ties.count, 0, sizeof(int), stream));
+    }
+    const KdTies* tp = (kd && m > 0) ? &ties : nullptr;
 
     bool use_grid = mode == ICPX_NN_GRID ||
                     (mode == ICPX_NN_AUTO && static_cast<double>(n) * static_cast<double>(m) > 512.0 * 1024 * 1024);  // measured crossover of one build + query: ~3e4 x 3e4
@@ -1430,15 +1446,15 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
         ICPX_HIP(hipGetLastError());
     } else if (mode == ICPX_NN_BVH) {
         if (!ws.bvh) ICPX_TRY(bvh_create(&ws.bvh));
-        ICPX_TRY(bvh_nn_oneshot(ws.bvh, dim, d_q, n, d_t, m, d_idx, d_d2, stream));
+        ICPX_TRY(bvh_nn_oneshot(ws.bvh, dim, d_q, n, d_t, m, d_idx, d_d2, stream, tp));
     } else if (use_grid) {
         if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
         if (mode == ICPX_NN_AUTO && !ws.bvh) ICPX_TRY(bvh_create(&ws.bvh));
-        ICPX_TRY(grid_nn_oneshot(ws.grid, dim, d_q, n, d_t, m, d_idx, d_d2, stream, mode == ICPX_NN_AUTO ? ws.bvh : nullptr));
+        ICPX_TRY(grid_nn_oneshot(ws.grid, dim, d_q, n, d_t, m, d_idx, d_d2, stream, mode == ICPX_NN_AUTO ? ws.bvh : nullptr, tp));
     } else {
         // (query tiles) x (target splits) so that the launch fills the chip; f32 filter + exact
         // refinement (nn_tile_kernel).  ICPX_FILTER=0 (development) selects the plain f64 kernel.
-        const bool plain = knobs().filter == 0;
+        const bool plain = knobs().filter == 0 && !kd;  // (the plain kernel has no tie detection)
         const int per_tile = plain ? kNnThreads * kNnQpt : kNnThreads * kNnTileQpt;
         const int qblocks = static_cast<int>((n + per_tile - 1) / per_tile);
         int splits = (4 * di->cus + qblocks - 1) / qblocks;
@@ -1483,25 +1499,39 @@ int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, in
                     aset[dev] = true;
                 }
             }
-            if (dim == 2)
-                hipLaunchKernelGGL(nn_tile_kernel<2>, grid, dim3(kNnThreads), lds, stream, d_q, n, d_t, m,
-                                   static_cast<int>(split_len), static_cast<int>(split_len), ws.part_d2.as<double>(),
-                                   ws.part_idx.as<int32_t>());
-            else
-                hipLaunchKernelGGL(nn_tile_kernel<3>, grid, dim3(kNnThreads), lds, stream, d_q, n, d_t, m,
-                                   static_cast<int>(split_len), static_cast<int>(split_len), ws.part_d2.as<double>(),
-                                   ws.part_idx.as<int32_t>());
+            auto tk = dim == 2 ? (kd ? nn_tile_kernel<2, true> : nn_tile_kernel<2, false>)
+                               : (kd ? nn_tile_kernel<3, true> : nn_tile_kernel<3, false>);
+            hipLaunchKernelGGL(tk, grid, dim3(kNnThreads), lds, stream, d_q, n, d_t, m, static_cast<int>(split_len),
+                               static_cast<int>(split_len), ws.part_d2.as<double>(), ws.part_idx.as<int32_t>());
         }
         ICPX_HIP(hipGetLastError());
         hipLaunchKernelGGL(nn_merge_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, n,
-                           splits, ws.part_d2.as<double>(), ws.part_idx.as<int32_t>(), d_idx, d_d2);
+                           splits, ws.part_d2.as<double>(), ws.part_idx.as<int32_t>(), d_idx, d_d2, dim, tp ? tp->cloud : nullptr,
+                           tp ? tp->list : nullptr, tp ? tp->count : nullptr);
         ICPX_HIP(hipGetLastError());
+    }
+    if (tp) {
+        ICPX_TRY(kd_resolve_queries(dim, d_q, n, d_t, m, ties, d_idx, stream));
+        if (d_d2) {
+            hipLaunchKernelGGL(nn_sqrt_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, n, d_d2);
+            ICPX_HIP(hipGetLastError());
+        }
     }
     if (idx && !idx_dev) ICPX_HIP(hipMemcpyAsync(idx, d_idx, sizeof(int64_t) * n, hipMemcpyDeviceToHost, stream));
     if (d2 && !d2_dev) ICPX_HIP(hipMemcpyAsync(d2, d_d2, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     ICPX_HIP(hipStreamSynchronize(stream));
     return ICPX_OK;
     });
+}
+
+int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+            int64_t* idx, double* d2, int mode, int device, void* stream_) {
+    return nn_impl(dim, queries, n, targets, m, idx, d2, mode, device, stream_, false);
+}
+
+int icpx_nn_kdtree(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+                   int64_t* idx, double* dist, int mode, int device, void* stream_) {
+    return nn_impl(dim, queries, n, targets, m, idx, dist, mode, device, stream_, true);
 }
 
 }  // extern "C"

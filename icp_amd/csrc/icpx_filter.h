@@ -39,7 +39,7 @@ struct LdsView {
 // block minimum is carried along (two more instructions per block), the winning block is counted at the end.
 template <int D, int QPT, bool KD = false>
 ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, double (&best)[QPT],
-                     int (&bidx)[QPT], bool* tie = nullptr) {
+                     int (&bidx)[QPT], int* tie = nullptr) {
     int bblk[QPT];
     double b2[KD ? QPT : 1];
 #pragma unroll
@@ -93,7 +93,7 @@ ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, dou
             }
         }
         bidx[k] = idx;
-        if (KD) tie[k] = best[k] < __builtin_inf() && (near > 1 || kd_near(b2[k], best[k]));
+        if (KD) tie[k] = (best[k] < __builtin_inf() && (near > 1 || kd_near(b2[k], best[k]))) ? 1 : 0;
     }
 }
 
@@ -164,7 +164,7 @@ ICPX_DEV float filter_threshold(double d2max, float qn_lo, float e_dist, float e
 // idle); j counts in the cloud (L.j0 + slot)
 // TIES (icpx_kd.h): *tie becomes true when another, non-coincident target lies within kKdNearUlps of the best
 template <int D, bool TIES = false>
-ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, double& best, int& bidx, bool* tie = nullptr) {
+ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, double& best, int& bidx, int* tie = nullptr) {
     const bool act = blk >= 0;
     const int jb = act ? blk : 0;
 #pragma unroll
@@ -180,7 +180,7 @@ ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, do
             acc = acc + df * df;
         }
         const int j = L.j0 + jb + u;
-        if (TIES) *tie = *tie || kd_tie_check<D>(act, acc, j, c, L.cloud, best, bidx);
+        if (TIES) *tie |= kd_tie_check<D>(act, acc, j, c, L.cloud, best, bidx) ? 1 : 0;
         bool better = act && (acc < best || (acc == best && j < bidx));
         best = better ? acc : best;
         bidx = better ? j : bidx;
@@ -367,20 +367,20 @@ ICPX_DEV void seed_bound(const double (&q)[QPT][D], const LdsView<D>& L, int m, 
 // TIES: tie[k] |= another non-coincident target within kKdNearUlps of slot k's minimum (icpx_kd.h)
 template <int D, int QPT, bool TIES = false>
 ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4, const FilterFrame& F,
-                          double (&best)[QPT], int (&bidx)[QPT], bool* tie = nullptr) {
+                          double (&best)[QPT], int (&bidx)[QPT], int* tie = nullptr) {
     float q2[QPT][D], qn[QPT], e_dist, e_val;
     const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
     if (__any(!ok)) {
         double lb[QPT];
         int li[QPT];
-        bool lt[TIES ? QPT : 1];
+        int lt[TIES ? QPT : 1];
         nn_lds<D, QPT, TIES>(q, L, m4, lb, li, TIES ? lt : nullptr);
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
             const int j = L.j0 + li[k];
             const bool take = lb[k] < best[k] || (lb[k] == best[k] && j < bidx[k]);
             // (coincident targets are not told apart here: a flag too many only costs the resolution's time)
-            if (TIES) tie[k] = tie[k] || lt[k] || (j != bidx[k] && lb[k] < __builtin_inf() && kd_near(lb[k], best[k]));
+            if (TIES) tie[k] |= lt[k] | ((j != bidx[k] && lb[k] < __builtin_inf() && kd_near(lb[k], best[k])) ? 1 : 0);
             best[k] = take ? lb[k] : best[k];
             bidx[k] = take ? j : bidx[k];
         }
@@ -435,7 +435,7 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4
 // lane.
 template <int D, bool TIES = false>
 ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D], float thr, const LdsView<D>& L,
-                          int m4, double& best, int& bidx, bool* tie = nullptr) {
+                          int m4, double& best, int& bidx, int* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     unsigned long long mask = __ballot(flag);
     while (mask) {
@@ -451,7 +451,7 @@ ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D],
         const float thr_b = __shfl(thr, src);
         double bb = __builtin_inf();
         int bi = 0x7fffffff;
-        bool lt = false;
+        int lt = 0;
         for (int jb = lane * 4; jb < m4; jb += 256) {
             f32x4 tc[D], tn;
             load_filter_block<D>(L, jb, tc, tn);
@@ -463,11 +463,11 @@ ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D],
             int oi = __shfl_xor(bi, o);
             bool take = ob < bb || (ob == bb && oi < bi);
             // (two lanes' minima within the tie range: flagged without the coincidence test of nn_take)
-            if (TIES) lt = lt || (oi != 0x7fffffff && bi != 0x7fffffff && oi != bi && ob < __builtin_inf() && kd_near(ob, bb));
+            if (TIES) lt |= (oi != 0x7fffffff && bi != 0x7fffffff && oi != bi && ob < __builtin_inf() && kd_near(ob, bb)) ? 1 : 0;
             bb = take ? ob : bb;
             bi = take ? oi : bi;
         }
-        if (TIES) lt = __any(lt);
+        if (TIES) lt = __any(lt != 0) ? 1 : 0;
         if (lane == src && bb < __builtin_inf()) {
             best = bb;
             bidx = bi;
@@ -485,7 +485,7 @@ ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D],
 // ties and near-ties inside the error budget — the query is rescanned cooperatively (coop_rescan).
 template <int D, int QPT, bool TIES = false>
 ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m4, const FilterFrame& F,
-                        double (&best)[QPT], int (&bidx)[QPT], bool* tie = nullptr) {
+                        double (&best)[QPT], int (&bidx)[QPT], int* tie = nullptr) {
     float q2[QPT][D], qn[QPT], e_dist, e_val;
     const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
     if (__any(!ok)) {
@@ -521,7 +521,7 @@ ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m4, 
     for (int k = 0; k < QPT; k++) {
         best[k] = __builtin_inf();
         bidx[k] = 0x7fffffff;
-        if (TIES) tie[k] = false;
+        if (TIES) tie[k] = 0;
         exact_block<D, TIES>(q[k], L, blk[k], best[k], bidx[k], TIES ? &tie[k] : nullptr);
         // near-ties (about 0.15 % of the queries on uniform clouds): cooperative rescan
         const float thr = filter_threshold(best[k], qn[k], e_dist, e_val);

@@ -11,6 +11,7 @@
 // (trimmed.cpp:95-109) — whatever the cell size and whatever the order of points inside a cell.
 #pragma once
 
+#include "icpx_kd.h"
 #include "icpx_math.h"
 
 namespace icpx {
@@ -244,9 +245,12 @@ __global__ void grid_scatter_kernel(const double* __restrict__ t, int64_t m, con
 // record r of the sequence is record r - pre[t] of the row t with pre[t] <= r < pre[t + 1].  A lane's records are
 // spread over several short rows, and row by row every row costs the wave a memory round trip of its own (config 4
 // converge 16.3 -> 14.3 ms).  (best, bidx): running (d2, index) minimum; bidx = 0x7fffffff while there is none.
-template <int D, int NR>
+// TIES (all searches of this file): tie |= another, non-coincident target lies within kKdNearUlps of the minimum
+// (icpx_kd.h; cloud = the targets in cloud order).  The stopping tests leave unvisited only what is farther than
+// (1 + 2^-41) times the best, so every tie partner is among the evaluated records.
+template <int D, int NR, bool TIES = false>
 ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, const int (&kb)[NR], const int (&ke)[NR],
-                             double& best, int& bidx, int& visited) {
+                             double& best, int& bidx, int& visited, int& tie, const double* __restrict__ cloud) {
     constexpr int kStep = 4;  // records in flight per lane (8: more registers, fewer waves, no gain — measured)
     int pre[NR], off[NR];
     int total = 0;
@@ -277,9 +281,8 @@ ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, 
                 dist = dist + df * df;
             }
             const int j = static_cast<int>(rec[u].idx);
-            const bool take = (r0 + u < total) && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
-            best = take ? dist : best;
-            bidx = take ? j : bidx;
+            const double cc[3] = {rec[u].x, rec[u].y, rec[u].z};
+            nn_take<TIES, D>(r0 + u < total, dist, j, cc, cloud, best, bidx, tie);
         }
     }
     visited += total;
@@ -292,9 +295,10 @@ ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, 
 // slabs exactly as in the shells' stopping test (same slack), so a row or cell is skipped only when everything in
 // it is strictly farther than the current best; cell ranges use cell_coord, the (monotone) function that placed
 // the targets.  best only shrinks, so everything at most as far as the final best is evaluated.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
-                             const double* q, const int (&c)[3], double& best, int& bidx, int& visited) {
+                             const double* q, const int (&c)[3], double& best, int& bidx, int& visited, int& tie,
+                             const double* __restrict__ cloud) {
     const double down = 0.99999999999909051;  // 1 - 2^-40
     double slack[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -343,9 +347,8 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ r
                         dist = dist + df * df;
                     }
                     const int j = static_cast<int>(rec[u].idx);
-                    const bool take = (k0 + u < ke) && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
-                    best = take ? dist : best;
-                    bidx = take ? j : bidx;
+                    const double cc[3] = {rec[u].x, rec[u].y, rec[u].z};
+                    nn_take<TIES, D>(k0 + u < ke, dist, j, cc, cloud, best, bidx, tie);
                 }
             }
             visited += ke - kb;
@@ -359,9 +362,10 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ r
 // tested and bounded exactly as in grid_ball_scan, but all their bounds are fetched before the first record (the
 // walk is a chain of memory latencies).  The candidate itself is among the visited targets, so the result is the
 // (d2, index) minimum over the whole cloud: what grid_query returns.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
-                                const double* q, double& best, int& bidx, int& visited) {
+                                const double* q, double& best, int& bidx, int& visited, int& tie,
+                                const double* __restrict__ cloud) {
     int c[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < D; d++) c[d] = cell_coord<D>(gp, q[d], d);
@@ -386,7 +390,7 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict_
     if (D == 3) range_of(2, rad, z0, z1);
     range_of(1, rad, y0, y1);
     if (z1 - z0 > 2 || y1 - y0 > 2) {
-        grid_ball_scan<D>(gp, recs, start, q, c, best, bidx, visited);
+        grid_ball_scan<D, TIES>(gp, recs, start, q, c, best, bidx, visited, tie, cloud);
         return;
     }
     constexpr int NR = D == 3 ? 9 : 3;
@@ -405,17 +409,17 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict_
         kb[t] = start[row + x0];
         ke[t] = in ? start[row + x1 + 1] : kb[t];
     }
-    grid_scan_rows<D, NR>(recs, q, kb, ke, best, bidx, visited);
+    grid_scan_rows<D, NR, TIES>(recs, q, kb, ke, best, bidx, visited, tie, cloud);
 }
 
 // one query against the grid.  Returns (best d2, lowest index among equal d2); (inf, 0) when no
 // target has a finite distance.
 // (r0, best0, bidx0): the shells below r0 have been visited already, with this result (grid_block_query)
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                          const int* __restrict__ start, const double* q, double& best_out,
-                         int& idx_out, int& visited, const int r0 = 0, const double best0 = __builtin_inf(),
-                         const int bidx0 = 0x7fffffff) {
+                         int& idx_out, int& visited, int& tie, const double* __restrict__ cloud, const int r0 = 0,
+                         const double best0 = __builtin_inf(), const int bidx0 = 0x7fffffff) {
     double best = best0;
     int bidx = bidx0;
     bool qfin = true;
@@ -448,7 +452,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                 kb[t] = start[row + xlo];
                 ke[t] = in ? start[row + xhi + 1] : kb[t];
             }
-            grid_scan_rows<D, NR>(recs, q, kb, ke, best, bidx, visited);
+            grid_scan_rows<D, NR, TIES>(recs, q, kb, ke, best, bidx, visited, tie, cloud);
             // the stopping test after shell 1 (as at the end of the loop below)
             double lb = __builtin_inf();
             bool all_covered = true;
@@ -473,7 +477,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
         for (int r = r_begin; r <= gp.rmax; r++) {
             if (r >= 2 && best < __builtin_inf()) {
                 // shells 0 and 1 did not settle it: the rest through the ball of the candidate
-                grid_ball_scan<D>(gp, recs, start, q, c, best, bidx, visited);
+                grid_ball_scan<D, TIES>(gp, recs, start, q, c, best, bidx, visited, tie, cloud);
                 break;
             }
             const int zlo = D == 3 ? (c[2] - r > 0 ? c[2] - r : 0) : 0;
@@ -525,11 +529,9 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                                     df = rec[u].z - q[2];
                                     dist = dist + df * df;
                                 }
-                                int j = static_cast<int>(rec[u].idx);
-                                bool take = (k0 + u < seg_e[s]) &&
-                                            (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
-                                best = take ? dist : best;
-                                bidx = take ? j : bidx;
+                                const int j = static_cast<int>(rec[u].idx);
+                                const double cc[3] = {rec[u].x, rec[u].y, rec[u].z};
+                                nn_take<TIES, D>(k0 + u < seg_e[s], dist, j, cc, cloud, best, bidx, tie);
                             }
                             visited += seg_e[s] - k0 < 4 ? seg_e[s] - k0 : 4;
                         }
@@ -673,10 +675,10 @@ ICPX_DEV bool grid_block_stage(const GridParams& gp, const GridRec* __restrict__
 }
 
 // One query of a staged block (staged: grid_block_stage returned true).  Per lane; no barriers.
-template <int D>
+template <int D, bool TIES = false>
 ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
                                const double* q, const bool staged, const int (&b0)[3], const int (&b1)[3], const char* lds,
-                               double& best_out, int& idx_out, int& visited) {
+                               double& best_out, int& idx_out, int& visited, int& tie, const double* __restrict__ cloud) {
     bool qfin = gp.m > 0;
 #pragma unroll
     for (int d = 0; d < D; d++) qfin = qfin && finite_d(q[d]);
@@ -693,7 +695,7 @@ ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__
         inside = inside && max(c[d] - 1, 0) >= b0[d] && min(c[d] + 1, gp.g[d] - 1) <= b1[d];
     }
     if (!inside) {
-        grid_query<D>(gp, recs, start, q, best_out, idx_out, visited);
+        grid_query<D, TIES>(gp, recs, start, q, best_out, idx_out, visited, tie, cloud);
         return;
     }
     const double* sx = reinterpret_cast<const double*>(lds);
@@ -717,9 +719,8 @@ ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__
                     dist = dist + df * df;
                 }
                 const int j = sidx[k];
-                const bool take = dist < best || (dist == best && j < bidx && bidx != 0x7fffffff);
-                best = take ? dist : best;
-                bidx = take ? j : bidx;
+                const double cc[3] = {sx[k], sx[kGridBlkRecs + k], D == 3 ? sx[2 * kGridBlkRecs + k] : 0.0};
+                nn_take<TIES, D>(true, dist, j, cc, cloud, best, bidx, tie);
             }
             visited += e - s;
         }
@@ -747,17 +748,23 @@ ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__
         best_out = best;
         idx_out = bidx == 0x7fffffff ? 0 : bidx;
     } else {
-        grid_query<D>(gp, recs, start, q, best_out, idx_out, visited, 2, best, bidx);
+        grid_query<D, TIES>(gp, recs, start, q, best_out, idx_out, visited, tie, cloud, 2, best, bidx);
     }
 }
 
 // stand-alone query, one workgroup per block of tiles
-template <int D>
+// kd_list / kd_count (TIES): the queries with a tie partner are appended (icpx_kd.h), for kd_resolve_kernel
+ICPX_DEV void kd_append(const int tie, const int64_t i, uint32_t* __restrict__ kd_list, int* __restrict__ kd_count) {
+    if (tie) kd_list[atomicAdd(kd_count, 1)] = static_cast<uint32_t>(i);
+}
+
+template <int D, bool TIES = false>
 __global__ void __launch_bounds__(256)
 grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec* __restrict__ recs,
                      const int* __restrict__ start, int64_t* __restrict__ idx, double* __restrict__ d2,
                      unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm,
-                     const int* __restrict__ qstart) {
+                     const int* __restrict__ qstart, const double* __restrict__ cloud = nullptr,
+                     uint32_t* __restrict__ kd_list = nullptr, int* __restrict__ kd_count = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     const int qs = qstart[blockIdx.x], qe = qstart[blockIdx.x + 1];
     if (qs >= qe) return;  // (uniform)
@@ -771,9 +778,11 @@ grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec*
         for (int d = 0; d < D; d++) qq[d] = q[i * D + d];
         double best;
         int bi;
-        grid_block_query<D>(gp, recs, start, qq, staged, b0, b1, grid_lds, best, bi, visited);
+        int tie = 0;
+        grid_block_query<D, TIES>(gp, recs, start, qq, staged, b0, b1, grid_lds, best, bi, visited, tie, cloud);
         if (idx) idx[i] = bi;
         if (d2) d2[i] = best;
+        if (TIES) kd_append(tie, i, kd_list, kd_count);
     }
     if (visited_total) {
         int v = wave_sum_int(visited);
@@ -781,11 +790,13 @@ grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec*
     }
 }
 
-template <int D>
+template <int D, bool TIES = false>
 __global__ void __launch_bounds__(256)
 grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const GridRec* __restrict__ recs,
                const int* __restrict__ start, int64_t* __restrict__ idx, double* __restrict__ d2,
-               unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm) {
+               unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm,
+               const double* __restrict__ cloud = nullptr, uint32_t* __restrict__ kd_list = nullptr,
+               int* __restrict__ kd_count = nullptr) {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     int visited = 0;
     const bool live = i < n;
@@ -797,9 +808,11 @@ grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const Gri
         for (int d = 0; d < D; d++) qq[d] = q[i * D + d];
         double best;
         int bi;
-        grid_query<D>(gp, recs, start, qq, best, bi, visited);
+        int tie = 0;
+        grid_query<D, TIES>(gp, recs, start, qq, best, bi, visited, tie, cloud);
         if (idx) idx[i] = bi;
         if (d2) d2[i] = best;
+        if (TIES) kd_append(tie, i, kd_list, kd_count);
     }
     if (visited_total) {
         int v = wave_sum_int(visited);

@@ -87,12 +87,14 @@ ICPX_DEV bool kd_tie_check(const bool valid, const double dist, const int j, con
     return near;
 }
 
-// (best, bidx) <- (d2, index) minimum with the candidate; KD: tie |= kd_tie_check
+// (best, bidx) <- (d2, index) minimum with the candidate; KD: tie |= kd_tie_check.
+// (tie is an int on purpose: carried as a bool through the irregular loop of the BVH walk it was miscompiled — a lane
+// mask merged across divergent control flow — and flags went missing; as a vector register it is plain data)
 template <bool KD, int D>
 ICPX_DEV void nn_take(const bool valid, const double dist, const int j, const double* c, const double* __restrict__ cloud,
-                      double& best, int& bidx, bool& tie) {
+                      double& best, int& bidx, int& tie) {
     const bool take = valid && (dist < best || (dist == best && j < bidx && bidx != 0x7fffffff));
-    if (KD) tie = tie || kd_tie_check<D>(valid, dist, j, c, cloud, best, bidx);
+    if (KD) tie |= kd_tie_check<D>(valid, dist, j, c, cloud, best, bidx) ? 1 : 0;
     best = take ? dist : best;
     bidx = take ? j : bidx;
 }

@@ -26,6 +26,20 @@ int large_transform(LargeIcp* lg, double* out);
 int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost);
 int large_neighbors(LargeIcp* lg, int64_t* idx, double* dist);
 
+// kd-tree tie rule of a stand-alone query (icpx_kd.h): the searches append the queries that have a tie partner
+struct KdTies {
+    const double* cloud = nullptr;  // the targets (device, AoS, cloud order)
+    uint32_t* list = nullptr;       // n entries (device)
+    int* count = nullptr;           // one word (device), cleared by the caller
+};
+// The reference's median-split tree (kdtree.h:96-116; equal coordinates ordered by index) of m host-resident points,
+// in in-order layout: node[p] = point at in-order position p, pos = its inverse.
+void kd_build_host(int dim, const double* pts, int64_t m, uint32_t* node, uint32_t* pos);
+// After a query with KdTies on `stream`: resolves the flagged queries (tree built on the host when there are any).
+// d_q: the queries, d_idx: their (d2, index) answers, corrected in place.  Synchronises the stream.
+int kd_resolve_queries(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, const KdTies& ties,
+                       int64_t* d_idx, hipStream_t stream);
+
 // Reusable search structure over one target cloud (device memory).
 struct GridIndex;
 int grid_create(GridIndex** out);
@@ -37,12 +51,12 @@ int grid_settle(GridIndex* g, hipStream_t stream, bool* rebuilt);
 // d_q / d_idx / d_d2: DEVICE pointers (idx, d2 may be null).  visited (device u64, may be null)
 // accumulates the number of candidate targets examined.
 int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
-                      unsigned long long* d_visited, hipStream_t stream);
+                      unsigned long long* d_visited, hipStream_t stream, const KdTies* ties = nullptr);
 int grid_profile(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, hipStream_t stream, double* out);
 struct BvhIndex;
 // degenerate_to (may be null): the index to use instead when the grid turns out degenerate (grid_degenerate)
 int grid_nn_oneshot(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m,
-                    int64_t* d_idx, double* d_d2, hipStream_t stream, BvhIndex* degenerate_to);
+                    int64_t* d_idx, double* d_d2, hipStream_t stream, BvhIndex* degenerate_to, const KdTies* ties = nullptr);
 
 // Linear BVH over one target cloud (icpx_bvh.h): the alternative index for clouds that fill their bounding box unevenly.
 struct BvhIndex;
@@ -51,6 +65,6 @@ void bvh_destroy(BvhIndex* b);
 // d_t: DEVICE pointer, AoS dim x m.  Synchronises the stream once (bounding box read-back).
 int bvh_build(BvhIndex* b, int dim, const double* d_t, int64_t m, hipStream_t stream);
 int bvh_nn_oneshot(BvhIndex* b, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m,
-                   int64_t* d_idx, double* d_d2, hipStream_t stream);
+                   int64_t* d_idx, double* d_d2, hipStream_t stream, const KdTies* ties = nullptr);
 
 }  // namespace icpx

@@ -17,16 +17,22 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <numeric>
+#include <thread>
 #include <unordered_map>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
 #include "icpx_filter.h"
 #include "icpx_bvh.h"
 #include "icpx_grid.h"
+#include "icpx_kd.h"
 #include "icpx_large.h"
 #include "icpx_math.h"
 
@@ -97,7 +103,24 @@ struct LargeDev {
     double fcent[2];
     int with_cost;    // the matches carry a cost that ICP::calculate_cost sums (2D; 3D with ICPX_FLAG_FILL_MATCHES)
     int update_cost;  // that cost changes in every iterate (not for reference 2D vanilla, Q1)
+    // kd-tree tie rule (icpx_kd.h): the correspondence kernels append the queries that have a tie partner
+    int kd_count;     // entries of the list (cleared by the kernel that ends an iteration)
+    int kd_ready;     // the target's tree is on the device: kd_resolve_kernel follows every correspondence step
+    int kd_stall;     // flagged queries but no tree yet: every kernel returns at once until the host has built it
+    int _pad2;
 };
+
+// every kernel of an iteration behind the correspondence stage begins with this
+ICPX_DEV bool lg_skip(const LargeDev* dev, int respect_done) { return (respect_done && dev->st.done) || dev->kd_stall != 0; }
+// ... and the first of them (lg_sum1) turns "flagged queries and no tree" into the stall, telling the host
+ICPX_DEV bool lg_kd_gate(LargeDev* dev, int* hflags) {
+    if (dev->kd_count == 0 || dev->kd_ready != 0) return false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dev->kd_stall = 1;
+        if (hflags) __hip_atomic_store(&hflags[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return true;
+}
 
 struct LargeIcp {
     int dim = 0, method = 0;
@@ -126,7 +149,11 @@ struct LargeIcp {
     // normalised feature-distance matrix, stored target-major ([j * n + i]) for coalesced reads
     bool feature = false;
     DevBuf f_rad, f_feat_a, f_feat_b, f_nfd;
-    int* h_done = nullptr;  // pinned: [0] done flag, [1] iterations finished (written by the device, large_converge polls)
+    // kd-tree tie rule (icpx_kd.h): flagged queries, and — once a correspondence step has flagged one — the target's tree
+    bool kd_rule = false;    // the method takes its neighbours from KdTree::search (vanilla 2D, both 3D)
+    bool kd_ready = false;   // kd_tree holds the tree of this begin()'s target cloud
+    DevBuf kd_list, kd_tree; // n query indices; [node m][pos m]
+    int* h_done = nullptr;  // pinned: [0] done flag, [1] iterations finished, [2] stalled at a tie (written by the device, large_converge polls)
     int* h_done_dev = nullptr;   // the same memory as the device sees it
     int* poll_dev = nullptr;     // h_done_dev while large_converge runs, else null: kernels then publish nothing
     // host time at which lg_init_kernel (which samples the device's start_clock) was enqueued: the
@@ -164,6 +191,16 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost
     dev->fmax_key = 0;
     dev->dmax_key = 0;
     dev->fcent[0] = dev->fcent[1] = 0.0;
+    dev->kd_count = 0;
+    dev->kd_ready = 0;
+    dev->kd_stall = 0;
+}
+
+// after the host has put the target's tree on the device (lg_kd_service): the stall ends
+__global__ void lg_kd_resume_kernel(LargeDev* dev) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    dev->kd_ready = 1;
+    dev->kd_stall = 0;
 }
 
 // NN stage.  MODE 0: the 3D per-iteration stage.  MODE 1: Vanilla::setup's compute_matches on the
@@ -175,14 +212,19 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost
 template <int D, int METHOD, int MODE>
 // (six waves per SIMD: the 80-register budget costs the per-lane walk nothing and hides more of its memory latency —
 // clustered config-4 converge 6.83 -> 6.55 ms; eight waves spill and lose)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+#ifndef ICPX_LG_NN_WAVES
+#define ICPX_LG_NN_WAVES 6
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPX_LG_NN_WAVES, 8)))
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
              double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh,
-             const double* __restrict__ seed_tgt) {
+             const double* __restrict__ seed_tgt, const double* __restrict__ cloud, uint32_t* __restrict__ kd_list) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
-    if (respect_done && dev->st.done) return;
+    // the kd-tree methods follow the reference tree's tie rule (icpx_kd.h): flagged queries go on kd_list
+    constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
+    if (lg_skip(dev, respect_done)) return;
     // the query of point i as the method defines it
     auto query_of = [&](const int64_t i, double (&q)[D]) {
         if (MODE == 1) {
@@ -211,8 +253,9 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
             for (int d = 0; d < D; d++) cur[i * D + d] = q[d];
         }
     };
-    auto publish = [&](const int64_t i, const double best, const int bi) {
+    auto publish = [&](const int64_t i, const double best, const int bi, const int tie) {
         nb_idx[i] = bi;
+        if (TIES && tie) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(i);
         if (MODE == 2) {
             nb_cost[i] = best;  // trimmed.cpp:101 squaredNorm; selection comes from lg_select_kernel
         } else {
@@ -232,8 +275,9 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         double q[D], best;
         int bi;
         query_of(i, q);
-        bvh_query<D>(bvh, top, q, best, bi, visited);
-        publish(i, best, bi);
+        int tie = 0;
+        bvh_query<D, TIES>(bvh, top, q, best, bi, visited, tie, cloud);
+        publish(i, best, bi, tie);
         return;
     }
     if (qstart) {
@@ -246,8 +290,9 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
             double q[D], best;
             int bi;
             query_of(i, q);
-            grid_block_query<D>(gp, recs, start, q, staged, b0, b1, grid_lds, best, bi, visited);
-            publish(i, best, bi);
+            int tie = 0;
+            grid_block_query<D, TIES>(gp, recs, start, q, staged, b0, b1, grid_lds, best, bi, visited, tie, cloud);
+            publish(i, best, bi, tie);
         }
         return;
     }
@@ -257,6 +302,7 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     double q[D], best;
     int bi;
     query_of(i, q);
+    int tie = 0;
     if (seed_tgt) {
         // nb_idx holds the neighbour of the previous correspondence step (the target cloud is seed_tgt): a candidate
         // whose ball bounds the search (grid_query_seeded).  Same (d2, index) minimum as the unseeded query.
@@ -275,13 +321,13 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         if (ok) {
             best = d2s;
             bi = static_cast<int>(s);
-            grid_query_seeded<D>(gp, recs, start, q, best, bi, visited);
-            publish(i, best, bi);
+            grid_query_seeded<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
+            publish(i, best, bi, tie);
             return;
         }
     }
-    grid_query<D>(gp, recs, start, q, best, bi, visited);
-    publish(i, best, bi);
+    grid_query<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
+    publish(i, best, bi, tie);
 }
 
 // ---- tiled brute-force correspondence for mid-size clouds --------------------------------------
@@ -329,7 +375,7 @@ __global__ void lg_apply_guess_kernel(const double* __restrict__ guess, const do
 
 template <int D>
 __global__ void lg_step_kernel(LargeDev* dev, int respect_done, double* __restrict__ cur, int64_t n) {
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // c = T * c with the step the previous iteration produced (identity after begin), vanilla_3d.cpp:91
@@ -353,7 +399,7 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
                   int64_t n, const double* __restrict__ dst, int64_t m, int split_len, int scap,
                   const int64_t* __restrict__ nb_idx, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
     extern __shared__ __attribute__((aligned(16))) double tile_lds[];
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     const int tid = threadIdx.x;
     const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
     const int mt = static_cast<int>(m - t0 < split_len ? m - t0 : split_len);
@@ -372,6 +418,8 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     float* f = reinterpret_cast<float*>(p);
     for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
     L.j0 = static_cast<int>(t0);
+    L.cloud = dst;
+    constexpr bool TIES = MODE != 2;  // the kd-tree methods (MODE 2 is trimmed ICP2: brute-force rule); icpx_kd.h
     // queries and seed indices first: their loads are in flight while the split is staged
     double q[QPT][D], best[QPT];
     int bidx[QPT];
@@ -420,14 +468,18 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
             bidx[k] = static_cast<int>(j);
         }
     }
-    if (seeded) nn_filtered<D, QPT>(q, L, m4, F, best, bidx);
-    else nn_twomin<D, QPT>(q, L, m4, F, best, bidx);
+    int tie[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; k++) tie[k] = 0;
+    if (seeded) nn_filtered<D, QPT, TIES>(q, L, m4, F, best, bidx, tie);
+    else nn_twomin<D, QPT, TIES>(q, L, m4, F, best, bidx, tie);
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
         const int64_t i = qbase + tid + k * kTileThreads;
         if (i < n) {
             part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = best[k];
-            part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = bidx[k];
+            // (the sign bit carries the split's tie flag to the merge; indices are below 2^29)
+            part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = bidx[k] | ((TIES && tie[k] != 0) ? static_cast<int>(0x80000000u) : 0);
         }
     }
 }
@@ -437,20 +489,33 @@ template <int D, int METHOD, int MODE>
 __global__ void __launch_bounds__(256)
 lg_tile_merge_kernel(LargeDev* dev, int respect_done, int64_t n, int splits, const double* __restrict__ part_d2,
                      const int32_t* __restrict__ part_idx, int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost,
-                     uint8_t* __restrict__ sel, double max_distance) {
-    if (respect_done && dev->st.done) return;
+                     uint8_t* __restrict__ sel, double max_distance, const double* __restrict__ cloud = nullptr,
+                     uint32_t* __restrict__ kd_list = nullptr) {
+    if (lg_skip(dev, respect_done)) return;
+    constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i == 0) dev->nn_valid = 1;
     if (i >= n) return;
     double best = part_d2[i];
     int32_t bi = part_idx[i];
+    bool tie = bi < 0;
+    bi &= 0x7fffffff;
     for (int s = 1; s < splits; s++) {
         double d = part_d2[static_cast<int64_t>(s) * n + i];
         int32_t j = part_idx[static_cast<int64_t>(s) * n + i];
+        tie = tie || j < 0;
+        j &= 0x7fffffff;
+        if (TIES && j != 0x7fffffff && bi != 0x7fffffff && j != bi && d < __builtin_inf() && kd_near(d, best)) {
+            // two splits' minima within the tie range: a tie unless the two targets coincide
+            bool same = d == best;
+            for (int e = 0; e < D && same; e++) same = cloud[static_cast<int64_t>(j) * D + e] == cloud[static_cast<int64_t>(bi) * D + e];
+            tie = tie || !same;
+        }
         bool take = d < best || (d == best && j < bi);
         best = take ? d : best;
         bi = take ? j : bi;
     }
+    if (TIES && tie && best < __builtin_inf()) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(i);
     if (bi == 0x7fffffff) bi = 0;  // nothing finite anywhere (non-finite input): the reference's untouched index
     nb_idx[i] = bi;
     if (MODE == 2) {
@@ -470,7 +535,7 @@ __global__ void lg_iota_kernel(int64_t n, uint32_t* __restrict__ v) {
 // trimmed.cpp:57-62: the first new_n matches of the sorted order are kept
 __global__ void lg_select_kernel(const LargeDev* dev, int respect_done, int64_t n, int64_t new_n,
                                  const uint32_t* __restrict__ order, uint8_t* __restrict__ sel) {
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r < n) sel[order[r]] = r < new_n ? 1 : 0;
 }
@@ -606,7 +671,7 @@ ICPX_DEV double key_to_f64(unsigned long long k) {
 // matching step that follows
 __global__ void fa_apply_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src,
                                 double* __restrict__ cur, int64_t n) {
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i == 0) dev->dmax_key = 0;
     if (i >= n) return;
@@ -713,7 +778,7 @@ __global__ void __launch_bounds__(256)
 fa_maxdist_kernel(LargeDev* dev, int respect_done, const double* __restrict__ cur, int64_t n,
                   const double* __restrict__ dst, int64_t m, int split_len) {
     __shared__ unsigned long long smax[4];
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
     const int64_t t1 = t0 + split_len < m ? t0 + split_len : m;
@@ -745,7 +810,7 @@ __global__ void __launch_bounds__(256)
 fa_match_kernel(const LargeDev* dev, int respect_done, const double* __restrict__ cur, int64_t n,
                 const double* __restrict__ dst, int64_t m, int split_len, const double* __restrict__ nfd,
                 double feature_weight, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
@@ -775,10 +840,11 @@ __global__ void __launch_bounds__(kBlk)
 lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
                const double* __restrict__ nb_cost, const uint8_t* __restrict__ sel, double* __restrict__ part,
-               int* __restrict__ cntp, int nblk, int groups) {
+               int* __restrict__ cntp, int nblk, int groups, int* hflags) {
     __shared__ double gs[(2 * D + 1) * 64];
     __shared__ int wcnt[kBlk / 64];
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
+    if (lg_kd_gate(dev, hflags)) return;  // flagged queries of the kd rule and no tree on the device yet: stall
     Xf<D> X;
 #pragma unroll
     for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
@@ -835,7 +901,7 @@ lg_fin1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
                int nblk) {
     __shared__ double lds[(2 * D + 1) * 64];
     __shared__ int wcnt[kBlk / 64];
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     double s[2 * D + 1];
     fin_tree_many<2 * D + 1>(part, nblk, lds, s);
     int c = 0;  // <= 2^24 selected points in all
@@ -862,7 +928,7 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
                const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
                const uint8_t* __restrict__ sel, double* __restrict__ part, int nblk, int groups) {
     __shared__ double gs[D * D * 64];
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     Xf<D> X;
 #pragma unroll
     for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
@@ -911,6 +977,8 @@ template <int D>
 __global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx_criteria crit,
                                        double clock_to_s, double host_elapsed_s, int* hflags) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (dev->kd_stall) return;
+    dev->kd_count = 0;
     double sum = dev->with_cost ? dev->cost_sum : 0.0;
     dev->st.cost = __builtin_sqrt(sum / static_cast<double>(n));  // icp.h:149-155
     if (check) {
@@ -932,7 +1000,7 @@ lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
                int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s, int* hflags) {
     __shared__ double lds[D * D * 64];
     constexpr int XN = (D + 1) * (D + 1);
-    if (respect_done && dev->st.done) return;
+    if (lg_skip(dev, respect_done)) return;
     double s[D * D];
     fin_tree_many<D * D>(part, nblk, lds, s);
     if (threadIdx.x == 0) {
@@ -953,6 +1021,7 @@ lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
             dev->step[e] = step.m[e];
         }
         dev->st.iteration_count += 1;
+        dev->kd_count = 0;
         // cost: 2D vanilla's matches never change (vanilla.cpp:80); ICP3 never fills them (Q4);
         // trimmed ICP2 rates the matches this iteration computed (icp.h:149-155)
         if (dev->update_cost) dev->st.cost = __builtin_sqrt(dev->cost_sum / n_points);
@@ -1240,29 +1309,29 @@ int grid_sort_queries(GridIndex* g, const double* d_q, int64_t n, hipStream_t st
 }
 
 int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
-                      unsigned long long* d_visited, hipStream_t stream) {
+                      unsigned long long* d_visited, hipStream_t stream, const KdTies* ties) {
     if (n <= 0) return ICPX_OK;
     const uint32_t* perm = g->q_perm_n == n ? g->q_perm.as<uint32_t>() : nullptr;
+    const double* cloud = ties ? ties->cloud : nullptr;
+    uint32_t* kl = ties ? ties->list : nullptr;
+    int* kc = ties ? ties->count : nullptr;
     // queries in tile order: one workgroup per block of tiles, its cells staged in LDS (icpx_grid.h)
     // — for clouds that fill their grid: with most cells empty (surfaces, clusters) the occupied blocks overflow the
     // staging area and the per-lane walk is faster (clustered config 4: 1.09 vs 1.49 ms)
     if (perm != nullptr && g->q_blocks > 0 && knobs().grid_coop != 0 && (g->occupied_frac >= 0.5 || knobs().grid_coop == 2)) {
-        if (g->dim == 2)
-            hipLaunchKernelGGL(grid_nn_block_kernel<2>, dim3(static_cast<unsigned>(g->q_blocks)), dim3(256), kGridBlkBytes, stream, d_q,
-                               g->gp, g->recs.as<GridRec>(), g->start.as<int>(), d_idx, d_d2, d_visited, perm, g->q_start.as<int>());
-        else
-            hipLaunchKernelGGL(grid_nn_block_kernel<3>, dim3(static_cast<unsigned>(g->q_blocks)), dim3(256), kGridBlkBytes, stream, d_q,
-                               g->gp, g->recs.as<GridRec>(), g->start.as<int>(), d_idx, d_d2, d_visited, perm, g->q_start.as<int>());
+        auto kern = g->dim == 2 ? (ties ? grid_nn_block_kernel<2, true> : grid_nn_block_kernel<2, false>)
+                                : (ties ? grid_nn_block_kernel<3, true> : grid_nn_block_kernel<3, false>);
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(g->q_blocks)), dim3(256), kGridBlkBytes, stream, d_q,
+                           g->gp, g->recs.as<GridRec>(), g->start.as<int>(), d_idx, d_d2, d_visited, perm, g->q_start.as<int>(),
+                           cloud, kl, kc);
         ICPX_HIP(hipGetLastError());
         return ICPX_OK;
     }
     const unsigned nb = static_cast<unsigned>((n + 255) / 256);
-    if (g->dim == 2)
-        hipLaunchKernelGGL(grid_nn_kernel<2>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
-                           g->start.as<int>(), d_idx, d_d2, d_visited, perm);
-    else
-        hipLaunchKernelGGL(grid_nn_kernel<3>, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
-                           g->start.as<int>(), d_idx, d_d2, d_visited, perm);
+    auto kern = g->dim == 2 ? (ties ? grid_nn_kernel<2, true> : grid_nn_kernel<2, false>)
+                            : (ties ? grid_nn_kernel<3, true> : grid_nn_kernel<3, false>);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, d_q, n, g->gp, g->recs.as<GridRec>(),
+                       g->start.as<int>(), d_idx, d_d2, d_visited, perm, cloud, kl, kc);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1305,16 +1374,16 @@ int grid_profile(GridIndex* g, int dim, const double* d_q, int64_t n, const doub
 }
 
 int grid_nn_oneshot(GridIndex* g, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
-                    double* d_d2, hipStream_t stream, BvhIndex* degenerate_to) {
+                    double* d_d2, hipStream_t stream, BvhIndex* degenerate_to, const KdTies* ties) {
     // the occupied-cell count of the build is read after the query order has been enqueued (grid_settle)
     int rc = grid_build(g, dim, d_t, m, stream, true);
     if (rc == ICPX_OK) rc = grid_sort_queries(g, d_q, n, stream);
     bool rebuilt = false;
     if (rc == ICPX_OK) rc = grid_settle(g, stream, &rebuilt);
     if (rc == ICPX_OK && degenerate_to != nullptr && grid_degenerate(g))
-        return bvh_nn_oneshot(degenerate_to, dim, d_q, n, d_t, m, d_idx, d_d2, stream);  // (declared in icpx_large.h)
+        return bvh_nn_oneshot(degenerate_to, dim, d_q, n, d_t, m, d_idx, d_d2, stream, ties);  // (declared in icpx_large.h)
     if (rc == ICPX_OK && rebuilt) rc = grid_sort_queries(g, d_q, n, stream);  // (the order was that of the coarser grid)
-    if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, d_idx, d_d2, nullptr, stream);
+    if (rc == ICPX_OK) rc = grid_query_launch(g, d_q, n, d_idx, d_d2, nullptr, stream, ties);
     if (rc == ICPX_OK) {
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
@@ -1436,27 +1505,117 @@ int bvh_sort_queries(BvhIndex* b, const double* d_q, int64_t n, hipStream_t stre
 }
 
 int bvh_query_launch(const BvhIndex* b, const double* d_q, int64_t n, int64_t* d_idx, double* d_d2,
-                     unsigned long long* d_visited, hipStream_t stream) {
+                     unsigned long long* d_visited, hipStream_t stream, const KdTies* ties = nullptr) {
     if (n <= 0) return ICPX_OK;
     const uint32_t* perm = b->q_perm_n == n ? b->q_perm.as<uint32_t>() : nullptr;
     const unsigned nb = static_cast<unsigned>((n + 255) / 256);
-    if (b->dim == 2)
-        hipLaunchKernelGGL(bvh_nn_kernel<2>, dim3(nb), dim3(256), 0, stream, d_q, n, b->view(), d_idx, d_d2, d_visited, perm);
-    else
-        hipLaunchKernelGGL(bvh_nn_kernel<3>, dim3(nb), dim3(256), 0, stream, d_q, n, b->view(), d_idx, d_d2, d_visited, perm);
+    auto kern = b->dim == 2 ? (ties ? bvh_nn_kernel<2, true> : bvh_nn_kernel<2, false>)
+                            : (ties ? bvh_nn_kernel<3, true> : bvh_nn_kernel<3, false>);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, stream, d_q, n, b->view(), d_idx, d_d2, d_visited, perm,
+                       ties ? ties->cloud : nullptr, ties ? ties->list : nullptr, ties ? ties->count : nullptr);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
 
 int bvh_nn_oneshot(BvhIndex* b, int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, int64_t* d_idx,
-                   double* d_d2, hipStream_t stream) {
+                   double* d_d2, hipStream_t stream, const KdTies* ties) {
     int rc = bvh_build(b, dim, d_t, m, stream);
     if (rc == ICPX_OK) rc = bvh_sort_queries(b, d_q, n, stream);
-    if (rc == ICPX_OK) rc = bvh_query_launch(b, d_q, n, d_idx, d_d2, nullptr, stream);
+    if (rc == ICPX_OK) rc = bvh_query_launch(b, d_q, n, d_idx, d_d2, nullptr, stream, ties);
     if (rc == ICPX_OK) {
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// kd-tree tie rule, host side (icpx_kd.h)
+// ------------------------------------------------------------------------------------------
+
+namespace {
+inline uint64_t kd_ord_key_host(double v) {
+    uint64_t b;
+    std::memcpy(&b, &v, sizeof(b));
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+// node[lo, hi): the subtree's points in any order -> in-order layout (kdtree.h:96-116 with std::nth_element, under the
+// total order (coordinate, index): the result does not depend on the standard library)
+void kd_build_range(int dim, const double* pts, uint32_t* node, int64_t lo, int64_t hi, int depth, int spawn) {
+    while (hi - lo > 1) {
+        const int axis = depth % dim;
+        const int64_t mid = lo + (hi - lo - 1) / 2;
+        std::nth_element(node + lo, node + mid, node + hi, [pts, dim, axis](uint32_t x, uint32_t y) {
+            const uint64_t kx = kd_ord_key_host(pts[static_cast<int64_t>(x) * dim + axis]);
+            const uint64_t ky = kd_ord_key_host(pts[static_cast<int64_t>(y) * dim + axis]);
+            return kx < ky || (kx == ky && x < y);
+        });
+        if (spawn > 0 && hi - lo > 32768) {
+            std::thread left(kd_build_range, dim, pts, node, lo, mid, depth + 1, spawn - 1);
+            kd_build_range(dim, pts, node, mid + 1, hi, depth + 1, spawn - 1);
+            left.join();
+            return;
+        }
+        kd_build_range(dim, pts, node, lo, mid, depth + 1, 0);
+        lo = mid + 1;
+        depth++;
+    }
+}
+}  // namespace
+
+void kd_build_host(int dim, const double* pts, int64_t m, uint32_t* node, uint32_t* pos) {
+    std::iota(node, node + m, 0u);
+    kd_build_range(dim, pts, node, 0, m, 0, 3);  // up to 8 threads on the top levels of large clouds
+    for (int64_t p = 0; p < m; p++) pos[node[p]] = static_cast<uint32_t>(p);
+}
+
+// tree of the device-resident cloud d_t into the two device arrays (each m entries); synchronises the stream
+int kd_tree_to_device(int dim, const double* d_t, int64_t m, uint32_t* d_node, uint32_t* d_pos, hipStream_t stream) {
+    std::vector<double> pts(static_cast<size_t>(m) * dim);
+    ICPX_HIP(hipMemcpyAsync(pts.data(), d_t, sizeof(double) * pts.size(), hipMemcpyDeviceToHost, stream));
+    ICPX_HIP(hipStreamSynchronize(stream));
+    std::vector<uint32_t> node(static_cast<size_t>(m)), pos(static_cast<size_t>(m));
+    kd_build_host(dim, pts.data(), m, node.data(), pos.data());
+    ICPX_HIP(hipMemcpyAsync(d_node, node.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, stream));
+    ICPX_HIP(hipMemcpyAsync(d_pos, pos.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, stream));
+    ICPX_HIP(hipStreamSynchronize(stream));  // (the host vectors go out of scope)
+    return ICPX_OK;
+}
+
+int kd_launch_resolve(int dim, const int* d_count, const uint32_t* d_list, int mode, const double* src, const double* cur,
+                      const double* xf, const uint32_t* d_node, const uint32_t* d_pos, const double* d_t, int64_t m,
+                      int64_t* d_idx, int blocks, hipStream_t stream) {
+    KdView<uint32_t> kd;
+    kd.node = d_node;
+    kd.pos = d_pos;
+    kd.pts = d_t;
+    kd.m = static_cast<int>(m);
+    if (dim == 2)
+        hipLaunchKernelGGL(kd_resolve_kernel<2>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx);
+    else
+        hipLaunchKernelGGL(kd_resolve_kernel<3>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx);
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+int kd_resolve_queries(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, const KdTies& ties,
+                       int64_t* d_idx, hipStream_t stream) {
+    int count = 0;
+    ICPX_HIP(hipMemcpyAsync(&count, ties.count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    ICPX_HIP(hipStreamSynchronize(stream));
+    if (std::getenv("ICPX_KD_DEBUG")) std::fprintf(stderr, "[icpx kd] stand-alone query: %d flagged of %lld\n", count, (long long)n);
+    if (count <= 0 || m <= 0 || d_idx == nullptr) return ICPX_OK;
+    DevBuf tree;
+    int rc = tree.reserve(sizeof(uint32_t) * 2 * static_cast<size_t>(m));
+    if (rc == ICPX_OK) rc = kd_tree_to_device(dim, d_t, m, tree.as<uint32_t>(), tree.as<uint32_t>() + m, stream);
+    if (rc == ICPX_OK)
+        rc = kd_launch_resolve(dim, ties.count, ties.list, 1, d_q, nullptr, nullptr, tree.as<uint32_t>(), tree.as<uint32_t>() + m, d_t, m,
+                               d_idx, count < 4096 ? count : 4096, stream);
+    if (rc == ICPX_OK) {
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    }
+    tree.release();
     return rc;
 }
 
@@ -1497,7 +1656,7 @@ void large_destroy(LargeIcp* lg) {
     (void)hipStreamSynchronize(lg->stream);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
                       &lg->cntp, &lg->dev, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
-                      &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd})
+                      &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree})
         b->release();
     grid_destroy(lg->grid);
     bvh_destroy(lg->bvh);
@@ -1516,7 +1675,7 @@ int enqueue_sums(LargeIcp* lg, int respect_done, bool second) {
         hipLaunchKernelGGL((lg_sum1_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->n,
                            lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(),
-                           lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups);
+                           lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups, lg->poll_dev);
         ICPX_HIP(hipGetLastError());
         hipLaunchKernelGGL(lg_fin1_kernel<D>, dim3(1), dim3(kBlk), 0, lg->stream, dev, respect_done,
                            lg->part.as<double>(), lg->cntp.as<int>(), nblk);
@@ -1594,8 +1753,28 @@ int enqueue_feature_setup(LargeIcp* lg) {
 }
 
 // the correspondence stage of one step: the tiled brute force (mid-size clouds) or the grid walk
+// kd rule: once the target's tree is on the device, the flagged queries of a correspondence step are resolved right
+// behind it (a launch that finds an empty list otherwise)
+template <int D, int MODE>
+int enqueue_kd_resolve(LargeIcp* lg) {
+    if (!lg->kd_rule || !lg->kd_ready || MODE == 2) return ICPX_OK;
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    return kd_launch_resolve(D, &dev->kd_count, lg->kd_list.as<uint32_t>(), MODE, lg->src.as<double>(), lg->cur.as<double>(),
+                             dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
+                             lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream);
+}
+
+template <int D, int METHOD, int MODE>
+int enqueue_nn_search(LargeIcp* lg, int respect);
+
 template <int D, int METHOD, int MODE>
 int enqueue_nn(LargeIcp* lg, int respect) {
+    ICPX_TRY((enqueue_nn_search<D, METHOD, MODE>(lg, respect)));
+    return enqueue_kd_resolve<D, MODE>(lg);
+}
+
+template <int D, int METHOD, int MODE>
+int enqueue_nn_search(LargeIcp* lg, int respect) {
     LargeDev* dev = lg->dev.as<LargeDev>();
     const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
     if (lg->feature) return enqueue_feature_match(lg, respect);
@@ -1605,7 +1784,8 @@ int enqueue_nn(LargeIcp* lg, int respect) {
             hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), sizeof(float) * 6 * kBvhTopNodes, lg->stream, dev,
                                respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, GridParams{}, nullptr, nullptr,
                                lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance,
-                               bv->q_perm_n == lg->n ? bv->q_perm.as<uint32_t>() : nullptr, nullptr, bv->view(), nullptr);
+                               bv->q_perm_n == lg->n ? bv->q_perm.as<uint32_t>() : nullptr, nullptr, bv->view(), nullptr,
+                               lg->dst.as<double>(), lg->kd_list.as<uint32_t>());
             ICPX_HIP(hipGetLastError());
             return ICPX_OK;
         }
@@ -1620,7 +1800,8 @@ int enqueue_nn(LargeIcp* lg, int respect) {
                            g->recs.as<GridRec>(), g->start.as<int>(), lg->nb_idx.as<int64_t>(),
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, perm,
                            blk ? g->q_start.as<int>() : nullptr, BvhView{},
-                           (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr);
+                           (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr,
+                           lg->dst.as<double>(), lg->kd_list.as<uint32_t>());
         ICPX_HIP(hipGetLastError());
         lg->nn_seeded = true;  // nb_idx now holds this step's neighbours
         return ICPX_OK;
@@ -1652,7 +1833,20 @@ int enqueue_nn(LargeIcp* lg, int respect) {
     ICPX_HIP(hipGetLastError());
     hipLaunchKernelGGL((lg_tile_merge_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n,
                        lg->splits, lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->nb_idx.as<int64_t>(),
-                       lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+                       lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, lg->dst.as<double>(),
+                       lg->kd_list.as<uint32_t>());
+    ICPX_HIP(hipGetLastError());
+    return ICPX_OK;
+}
+
+// what follows the correspondence step of setup (also: what remains of it after a stall at a tie, lg_kd_service)
+template <int D, int METHOD>
+int enqueue_setup_tail(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const bool fill3 = D == 3 && (lg->prm.flags & ICPX_FLAG_FILL_MATCHES);
+    if (D == 2 || fill3) ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
+    hipLaunchKernelGGL(lg_setup_finish_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, check, crit,
+                       lg->clock_to_s, host_elapsed_s, lg->poll_dev);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1672,24 +1866,29 @@ int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double hos
         if (lg->feature) ICPX_TRY(enqueue_feature_setup(lg));
         if (match_tf) ICPX_TRY((enqueue_nn<D, METHOD, 3>(lg, 0)));
         else ICPX_TRY((enqueue_nn<D, METHOD, METHOD == ICPX_TRIMMED ? 2 : 1>(lg, 0)));
-        ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
     } else if (fill3) {
         // opt-in: the 3D methods fill `matches` in setup too (step is the identity here)
         ICPX_TRY((enqueue_nn<D, METHOD, 0>(lg, 0)));
-        ICPX_TRY((enqueue_sums<D, METHOD>(lg, 0, false)));
     }
-    hipLaunchKernelGGL(lg_setup_finish_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, check, crit,
-                       lg->clock_to_s, host_elapsed_s, lg->poll_dev);
-    ICPX_HIP(hipGetLastError());
-    return ICPX_OK;
+    return enqueue_setup_tail<D, METHOD>(lg, check, crit, host_elapsed_s);
 }
 
 template <int D, int METHOD>
+int enqueue_iteration_tail(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s);
+
+template <int D, int METHOD>
 int enqueue_iteration(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
-    LargeDev* dev = lg->dev.as<LargeDev>();
     const int respect = check;
     if (D == 3 || METHOD == ICPX_TRIMMED) ICPX_TRY((enqueue_nn<D, METHOD, D == 3 ? 0 : 2>(lg, respect)));
     else if (lg->prm.flags & ICPX_FLAG_MATCH_TRANSFORMED) ICPX_TRY((enqueue_nn<D, METHOD, 3>(lg, respect)));
+    return enqueue_iteration_tail<D, METHOD>(lg, check, crit, host_elapsed_s);
+}
+
+// what follows the correspondence step of an iteration (also: what remains of it after a stall at a tie)
+template <int D, int METHOD>
+int enqueue_iteration_tail(LargeIcp* lg, int check, const icpx_criteria& crit, double host_elapsed_s) {
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    const int respect = check;
     if (D == 2 && METHOD == ICPX_TRIMMED) {
         // std::sort by cost (trimmed.cpp:55-56) made total: a stable LSD radix sort over the
         // cost's bit pattern (costs are >= 0, so bit order is numeric order) with the point index
@@ -1728,6 +1927,50 @@ icpx_criteria zero_criteria() {
 
 }  // namespace
 
+namespace {
+// kd rule, host side of a stall.  Precondition: the stream is idle.  *stalled: the device had stopped at flagged
+// queries without a tree; now the tree is on the device, the flagged queries are being resolved and the stall is
+// over — the caller enqueues what remained of the stalled step.  mode: MODE of the stalled correspondence step.
+int lg_kd_service(LargeIcp* lg, int mode, bool* stalled) {
+    *stalled = false;
+    if (!lg->kd_rule || lg->kd_ready) return ICPX_OK;
+    LargeDev* dev = lg->dev.as<LargeDev>();
+    int stall = 0;
+    ICPX_HIP(hipMemcpyAsync(&stall, &dev->kd_stall, sizeof(int), hipMemcpyDeviceToHost, lg->stream));
+    ICPX_HIP(hipStreamSynchronize(lg->stream));
+    if (std::getenv("ICPX_KD_DEBUG")) {
+        int cnt = -1, rdy = -1;
+        (void)hipMemcpy(&cnt, &dev->kd_count, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&rdy, &dev->kd_ready, sizeof(int), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[icpx kd] service: stall %d count %d ready %d mode %d bvh %d tile %d\n", stall, cnt, rdy, mode, (int)lg->use_bvh, (int)lg->tile);
+        if (cnt > 0 && cnt < 200) {
+            std::vector<uint32_t> l(cnt);
+            (void)hipMemcpy(l.data(), lg->kd_list.p, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost);
+            std::sort(l.begin(), l.end());
+            std::fprintf(stderr, "[icpx kd] list:");
+            for (uint32_t v : l) std::fprintf(stderr, " %u", v);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    if (!stall) return ICPX_OK;
+    ICPX_TRY(lg->kd_tree.reserve(sizeof(uint32_t) * 2 * static_cast<size_t>(lg->m)));
+    ICPX_TRY(kd_tree_to_device(lg->dim, lg->dst.as<double>(), lg->m, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m, lg->stream));
+    lg->kd_ready = true;
+    hipLaunchKernelGGL(lg_kd_resume_kernel, dim3(1), dim3(64), 0, lg->stream, dev);
+    ICPX_HIP(hipGetLastError());
+    ICPX_TRY(kd_launch_resolve(lg->dim, &dev->kd_count, lg->kd_list.as<uint32_t>(), mode, lg->src.as<double>(), lg->cur.as<double>(),
+                               dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
+                               lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream));
+    *stalled = true;
+    return ICPX_OK;
+}
+int lg_iteration_mode(const LargeIcp* lg) { return lg->dim == 3 ? 0 : 3; }
+int lg_setup_mode(const LargeIcp* lg) {
+    if (lg->dim == 3) return 0;
+    return (lg->prm.flags & ICPX_FLAG_MATCH_TRANSFORMED) ? 3 : 1;
+}
+}  // namespace
+
 int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* target, int64_t m,
                 const double* guess) {
     const int D = lg->dim;
@@ -1761,6 +2004,9 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     ICPX_HIP(hipMemsetAsync(lg->sel.p, 1, n, lg->stream));
     lg->sorted = false;
     lg->feature = D == 2 && lg->method == ICPX_FEATURE_AWARE;
+    lg->kd_rule = !lg->feature && (D == 3 || lg->method == ICPX_VANILLA);
+    lg->kd_ready = false;
+    if (lg->kd_rule) ICPX_TRY(lg->kd_list.reserve(sizeof(uint32_t) * n));
     if (D == 2 && lg->method != ICPX_VANILLA) {
         // trimmed.cpp:57-58, feature_aware.cpp:92-93 (overlap_rate > 1 would read out of range there; clamped here)
         long long k = static_cast<long long>(lg->prm.overlap_rate * static_cast<double>(n));
@@ -1842,12 +2088,23 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         ICPX_TRY(lg->f_feat_b.reserve(sizeof(double) * (w * m + 1)));
         ICPX_TRY(lg->f_nfd.reserve(sizeof(double) * static_cast<size_t>(n) * m));
     }
-    return LG_DISPATCH(enqueue_setup, lg, 0, zero_criteria(), 0.0);
+    ICPX_TRY(LG_DISPATCH(enqueue_setup, lg, 0, zero_criteria(), 0.0));
+    if (lg->kd_rule && (D == 2 || (lg->prm.flags & ICPX_FLAG_FILL_MATCHES))) {
+        // setup ran a correspondence step: it may have stopped at a tie of the kd rule
+        bool stalled = false;
+        ICPX_TRY(lg_kd_service(lg, lg_setup_mode(lg), &stalled));
+        if (stalled) ICPX_TRY(LG_DISPATCH(enqueue_setup_tail, lg, 0, zero_criteria(), 0.0));
+    }
+    return ICPX_OK;
 }
 
 int large_iterate(LargeIcp* lg) {
     lg->sorted = true;
-    return LG_DISPATCH(enqueue_iteration, lg, 0, zero_criteria(), 0.0);
+    ICPX_TRY(LG_DISPATCH(enqueue_iteration, lg, 0, zero_criteria(), 0.0));
+    bool stalled = false;
+    ICPX_TRY(lg_kd_service(lg, lg_iteration_mode(lg), &stalled));  // (no-op once the tree is on the device)
+    if (stalled) ICPX_TRY(LG_DISPATCH(enqueue_iteration_tail, lg, 0, zero_criteria(), 0.0));
+    return ICPX_OK;
 }
 
 int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_clock::time_point t0,
@@ -1868,6 +2125,7 @@ int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_
     lg->poll_dev = knobs().poll_done != 0 ? lg->h_done_dev : nullptr;
     lg->h_done[0] = 0;
     lg->h_done[1] = -1;
+    lg->h_done[2] = 0;
     if (lg->dim == 2)
         hipLaunchKernelGGL(lg_setup_finish_kernel<2>, dim3(1), dim3(64), 0, lg->stream, dev, lg->n, 1, *crit,
                            lg->clock_to_s, elapsed(), lg->poll_dev);
@@ -1878,12 +2136,13 @@ int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_
     uint64_t enq = 0;
     int chunk = 4;
     while (true) {
-        // wait until the device reports `done` or all `enq` iterations enqueued so far
+        // wait until the device reports `done`, a stall at a tie of the kd rule, or all `enq` iterations enqueued so far
         bool have = false;
         if (lg->poll_dev) {
             for (uint64_t spin = 1;; spin++) {
                 const int ticks = __atomic_load_n(&lg->h_done[1], __ATOMIC_ACQUIRE);
-                if (__atomic_load_n(&lg->h_done[0], __ATOMIC_ACQUIRE) != 0 || (ticks >= 0 && static_cast<uint64_t>(ticks) >= enq)) {
+                if (__atomic_load_n(&lg->h_done[0], __ATOMIC_ACQUIRE) != 0 || __atomic_load_n(&lg->h_done[2], __ATOMIC_ACQUIRE) != 0 ||
+                    (ticks >= 0 && static_cast<uint64_t>(ticks) >= enq)) {
                     have = true;
                     break;
                 }
@@ -1892,7 +2151,8 @@ int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_
                     if (q == hipSuccess) {
                         // the stream has drained: its kernels' stores are visible now (or never came: read the flag the patient way)
                         const int t2 = __atomic_load_n(&lg->h_done[1], __ATOMIC_ACQUIRE);
-                        have = __atomic_load_n(&lg->h_done[0], __ATOMIC_ACQUIRE) != 0 || (t2 >= 0 && static_cast<uint64_t>(t2) >= enq);
+                        have = __atomic_load_n(&lg->h_done[0], __ATOMIC_ACQUIRE) != 0 || __atomic_load_n(&lg->h_done[2], __ATOMIC_ACQUIRE) != 0 ||
+                               (t2 >= 0 && static_cast<uint64_t>(t2) >= enq);
                         break;
                     }
                     if (q != hipErrorNotReady) return fail(ICPX_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
@@ -1902,6 +2162,23 @@ int large_converge(LargeIcp* lg, const icpx_criteria* crit, std::chrono::steady_
         if (!have) {
             ICPX_HIP(hipMemcpyAsync(lg->h_done, &dev->st.done, sizeof(int), hipMemcpyDeviceToHost, lg->stream));
             ICPX_HIP(hipStreamSynchronize(lg->stream));
+        }
+        if (!lg->h_done[0] && lg->kd_rule && !lg->kd_ready) {
+            // (without the polled flags the stall shows only in device memory: lg_kd_service reads it)
+            bool stalled = false;
+            if (lg->h_done[2] || !have || !lg->poll_dev) {
+                ICPX_HIP(hipStreamSynchronize(lg->stream));  // the kernels enqueued behind the stall return at once
+                ICPX_TRY(lg_kd_service(lg, lg_iteration_mode(lg), &stalled));
+            }
+            if (stalled) {
+                uint64_t it = 0;
+                ICPX_HIP(hipMemcpyAsync(&it, &dev->st.iteration_count, sizeof(it), hipMemcpyDeviceToHost, lg->stream));
+                ICPX_HIP(hipStreamSynchronize(lg->stream));
+                lg->h_done[2] = 0;
+                ICPX_TRY(LG_DISPATCH(enqueue_iteration_tail, lg, 1, *crit, elapsed()));  // the rest of the stalled iteration
+                enq = it + 1;
+                continue;
+            }
         }
         if (lg->h_done[0]) break;
         uint64_t k = static_cast<uint64_t>(chunk);

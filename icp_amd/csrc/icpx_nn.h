@@ -119,7 +119,8 @@ inline size_t nn_tile_lds_bytes(int dim, int scap) {
     return sizeof(double) * (static_cast<size_t>(dim) * scap + kNnScratch) + sizeof(float) * static_cast<size_t>(dim) * scap;
 }
 
-template <int D>
+// TIES: the kd-tree rule's tie detection (icpx_kd.h); the split's flag travels in the sign bit of part_idx.
+template <int D, bool TIES = false>
 __global__ void __launch_bounds__(kNnThreads)
 nn_tile_kernel(const double* __restrict__ q, int64_t n, const double* __restrict__ t, int64_t m, int split_len, int scap,
                double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
@@ -142,6 +143,7 @@ nn_tile_kernel(const double* __restrict__ q, int64_t n, const double* __restrict
     float* f = reinterpret_cast<float*>(p);
     for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
     L.j0 = static_cast<int>(t0);
+    L.cloud = t;
     double qq[kNnTileQpt][D], best[kNnTileQpt];
     int bidx[kNnTileQpt];
     const int64_t qbase = static_cast<int64_t>(blockIdx.x) * (kNnThreads * kNnTileQpt);
@@ -152,7 +154,10 @@ nn_tile_kernel(const double* __restrict__ q, int64_t n, const double* __restrict
         for (int d = 0; d < D; d++) qq[k][d] = i < n ? q[i * D + d] : 0.0;
     }
     const FilterFrame F = stage_targets<D>(t + t0 * D, mt, m4, kNnThreads, L, true);
-    nn_twomin<D, kNnTileQpt>(qq, L, m4, F, best, bidx);
+    int tie[kNnTileQpt];
+#pragma unroll
+    for (int k = 0; k < kNnTileQpt; k++) tie[k] = 0;
+    nn_twomin<D, kNnTileQpt, TIES>(qq, L, m4, F, best, bidx, tie);
 #pragma unroll
     for (int k = 0; k < kNnTileQpt; k++) {
         const int64_t i = qbase + tid + k * kNnThreads;
@@ -160,29 +165,50 @@ nn_tile_kernel(const double* __restrict__ q, int64_t n, const double* __restrict
             // a split without any finite distance reports (inf, its first index), as nn_brute_kernel does
             const bool none = !(best[k] < __builtin_inf());
             part_d2[static_cast<int64_t>(blockIdx.y) * n + i] = none ? __builtin_inf() : best[k];
-            part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = none ? static_cast<int>(t0) : bidx[k];
+            part_idx[static_cast<int64_t>(blockIdx.y) * n + i] =
+                none ? static_cast<int>(t0) : (bidx[k] | ((TIES && tie[k] != 0) ? static_cast<int>(0x80000000u) : 0));
         }
     }
 }
 
 // splits are ordered by target index and each partial already holds its lowest index, so a
 // strict < in split order keeps the lexicographic (d2, index) minimum.
+// kd_list / kd_count (null: none): queries with a tie partner of the kd rule — flagged by a split, or two splits'
+// minima within the tie range of each other (cloud: the targets, dim D, to tell coincident targets apart)
 __global__ void nn_merge_kernel(int64_t n, int splits, const double* __restrict__ part_d2,
                                 const int32_t* __restrict__ part_idx, int64_t* __restrict__ idx,
-                                double* __restrict__ d2) {
+                                double* __restrict__ d2, int D = 0, const double* __restrict__ cloud = nullptr,
+                                uint32_t* __restrict__ kd_list = nullptr, int* __restrict__ kd_count = nullptr) {
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double best = part_d2[i];
     int32_t bi = part_idx[i];
+    bool tie = bi < 0;
+    bi &= 0x7fffffff;
     for (int s = 1; s < splits; s++) {
         double d = part_d2[static_cast<int64_t>(s) * n + i];
+        int32_t j = part_idx[static_cast<int64_t>(s) * n + i];
+        tie = tie || j < 0;
+        j &= 0x7fffffff;
+        if (kd_list && d < __builtin_inf() && kd_near(d, best)) {
+            bool same = d == best;
+            for (int e = 0; e < D && same; e++) same = cloud[static_cast<int64_t>(j) * D + e] == cloud[static_cast<int64_t>(bi) * D + e];
+            tie = tie || !same;
+        }
         if (d < best) {
             best = d;
-            bi = part_idx[static_cast<int64_t>(s) * n + i];
+            bi = j;
         }
     }
     if (idx) idx[i] = bi;
     if (d2) d2[i] = best;
+    if (kd_list && tie && best < __builtin_inf()) kd_list[atomicAdd(kd_count, 1)] = static_cast<uint32_t>(i);
+}
+
+// Euclidean distances from squared ones (KdTree::search returns sqrt, kdtree.h:126)
+__global__ void nn_sqrt_kernel(int64_t n, double* __restrict__ d) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = __builtin_sqrt(d[i]);
 }
 
 // no targets at all: every query gets (index 0, +inf) — what the search loops leave when nothing is below +inf

@@ -764,11 +764,11 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     bool kd_ready = (reinterpret_cast<int*>(L.bc + 41)[0] & 1) != 0;
     bool kd_resume = KD && pb.kd_takeover != 0;
     // KD kernels: flagged queries of one search are resolved here, by the whole workgroup (barriers)
-    auto kd_fix = [&](const double (&q)[QPT][D], const double (&best)[QPT], int (&pair_)[QPT], const bool (&tie)[QPT],
+    auto kd_fix = [&](const double (&q)[QPT][D], const double (&best)[QPT], int (&pair_)[QPT], const int (&tie)[QPT],
                       const bool (&valid_)[QPT]) {
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < QPT; k++) any = any || (tie[k] && valid_[k]);
+        for (int k = 0; k < QPT; k++) any = any || (tie[k] != 0 && valid_[k]);
         if (!block_any(any, any_word)) return;
         if (!kd_ready) {
             kd_build_lds<D, uint16_t>(dst, m, reinterpret_cast<char*>(L.t[0]), pb.kdnode + d0, pb.kdpos + d0);
@@ -784,7 +784,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
             int sl = pair_[k];
-            kd_resolve_wave<D, uint16_t>(tie[k] && valid_[k], q[k], best[k], L, m, nullptr, kd, sl);
+            kd_resolve_wave<D, uint16_t>(tie[k] != 0 && valid_[k], q[k], best[k], L, m, nullptr, kd, sl);
             pair_[k] = sl;
         }
     };
@@ -822,7 +822,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
             }
             double best[QPT];
             if constexpr (KD) {
-                bool tie[QPT];
+                int tie[QPT];
                 nn_lds<D, QPT, true>(q, L, m4, best, pair, tie);
                 kd_fix(q, best, pair, tie, valid);
             } else {
@@ -952,9 +952,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++)
 #pragma unroll
                     for (int d = 0; d < D; d++) cur[k][d] = a[k][d];
-                bool tie[QPT];
+                int tie[QPT];
 #pragma unroll
-                for (int k = 0; k < QPT; k++) tie[k] = false;
+                for (int k = 0; k < QPT; k++) tie[k] = 0;
                 if constexpr (KD) {
                     nn_lds<D, QPT, true>(cur, L, m4, best, pair, tie);
                     kd_fix(cur, best, pair, tie, valid);
@@ -967,7 +967,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                     if (TIES) {
                         bool any = false;
 #pragma unroll
-                        for (int k = 0; k < QPT; k++) any = any || (tie[k] && valid[k]);
+                        for (int k = 0; k < QPT; k++) any = any || (tie[k] != 0 && valid[k]);
                         if (block_any(any, any_word)) {
                             // a flagged query: this kernel cannot resolve it.  Nothing of this iteration has been
                             // stored yet; hand the pair over as it stood before it

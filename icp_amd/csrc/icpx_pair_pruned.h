@@ -142,7 +142,7 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
     // c[k] (3D, vanilla_3d.cpp:30-45) or X * a[k] (2D, trimmed.cpp:41,95-109); results into pv / costv.
     // selm: 3D trimmed — bit k set when the neighbour is within max_distance (trimmed_3d.cpp:98).
     constexpr bool TIES = D == 3;  // the kd-tree methods: detect the tie rule's cases (icpx_kd.h); 2D here is trimmed (brute-force rule)
-    bool kd_tie = false;
+    int kd_tie = 0;
     auto search = [&](const bool seeded, int& selm) __attribute__((always_inline)) {
         const XfRows<D> xr = xf_rows<D>(X);
         selm = 0;
@@ -253,7 +253,7 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
             search(have_seed, selm);
             have_seed = true;
             if (TIES) {
-                if (block_any(kd_tie, reinterpret_cast<int*>(L.bc + 42))) {
+                if (block_any(kd_tie != 0, reinterpret_cast<int*>(L.bc + 42))) {
                     // a query met the kd rule's tie case, which this kernel only detects: the pair stops here, as it stood
                     // before this iteration (nothing of it has been stored), and the KD kernel behind takes it over
                     if (tid == 0) {

@@ -78,7 +78,7 @@ ICPX_DEV bool slot_tie(const bool act, const double acc, const int j, const doub
 }
 
 template <int D, bool TIES = false>
-ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
+ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const GridView& P, double& best, int& bslot, int* tie = nullptr) {
     double b = __builtin_inf();
     int bs = 0, bo = 0x7fffffff, zslot = 0;
     for (int j = 0; j < P.m; j++) {
@@ -91,7 +91,7 @@ ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const Grid
         }
         const int o = P.tperm[j];
         zslot = o == 0 ? j : zslot;
-        if (TIES) *tie = *tie || slot_tie<D>(bo != 0x7fffffff, acc, j, b, bs, L);
+        if (TIES) *tie |= slot_tie<D>(bo != 0x7fffffff, acc, j, b, bs, L) ? 1 : 0;
         const bool better = acc < b || (acc == b && acc < __builtin_inf() && o < bo);
         b = better ? acc : b;
         bs = better ? j : bs;
@@ -105,7 +105,7 @@ ICPX_DEV void exact_scan_p(const double (&q)[D], const LdsView<D>& L, const Grid
 // exact (d2, cloud index) update with the target in slot j
 template <int D, bool TIES = false>
 ICPX_DEV void grid_eval(const double (&q)[D], const bool act, const int j, const LdsView<D>& L, const GridView& P,
-                        double& best, int& bslot, bool* tie = nullptr) {
+                        double& best, int& bslot, int* tie = nullptr) {
     double df = L.t[0][j] - q[0];
     double acc = df * df;
 #pragma unroll
@@ -113,7 +113,7 @@ ICPX_DEV void grid_eval(const double (&q)[D], const bool act, const int j, const
         df = L.t[d][j] - q[d];
         acc = acc + df * df;
     }
-    if (TIES) *tie = *tie || slot_tie<D>(act, acc, j, best, bslot, L);
+    if (TIES) *tie |= slot_tie<D>(act, acc, j, best, bslot, L) ? 1 : 0;
     bool better = act && acc < best;
     const bool eq = act && acc == best && j != bslot && bslot >= 0;
     if (__any(eq)) {
@@ -129,7 +129,7 @@ ICPX_DEV void grid_eval(const double (&q)[D], const bool act, const int j, const
 // bslot < 0 = none yet.
 template <int D, bool TIES = false>
 ICPX_DEV void grid_walk(const double (&q)[D], bool act, const int (&c0)[D], const int (&c1)[D], const LdsView<D>& L,
-                        const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
+                        const GridView& P, double& best, int& bslot, int* tie = nullptr) {
     const int G = P.g.G;
     int cy = c0[1], cz = D == 3 ? c0[D - 1] : 0;
     int j = 0, e = 0;
@@ -238,7 +238,7 @@ ICPX_DEV bool seed_certified(double d2_seed, double hc) {
 // target on entry.  Out: lexicographic minimum of (d2, cloud index) over all targets, as its slot.
 template <int D, bool TIES = false>
 ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded, const LdsView<D>& L,
-                           const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
+                           const GridView& P, double& best, int& bslot, int* tie = nullptr) {
     bool fin = P.g.bad == 0;
 #pragma unroll
     for (int d = 0; d < D; d++) fin = fin && (__builtin_fabs(q[d]) < 1e150);
@@ -376,7 +376,7 @@ ICPX_DEV int wave_incl_scan(int v) {
 // coincide with the others.  The (d2, cloud index) answer is unchanged.
 template <int D, int NR, bool TIES = false>
 ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR], const int (&rl)[NR], const int nrows,
-                        const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl, bool* tie = nullptr) {
+                        const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl, int* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     ICPX_CYC_BEGIN();
 #pragma unroll
@@ -553,7 +553,7 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
         if (total > 0) {
             rb = __longlong_as_double(static_cast<long long>(S.accd[lane]));
             rsl = static_cast<int>(S.acci[lane] & 0xffffu);
-            if (TIES) *tie = *tie || S.acct[lane] != 0u;
+            if (TIES) *tie |= S.acct[lane] != 0u ? 1 : 0;
         } else {
             rb = __builtin_inf();
             rsl = -1;
@@ -567,7 +567,7 @@ ICPX_DEV void coop_pass(const double (&q)[D], const bool grp, const int (&rs)[NR
 // lane's box was taken; the others (`big`) are the caller's business.
 template <int D, bool TIES = false>
 ICPX_DEV bool coop_box(const double (&q)[D], const bool act, const int (&c0)[D], const int (&c1)[D],
-                       const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl, bool* tie = nullptr) {
+                       const LdsView<D>& L, const GridView& P, const CoopStage<D>& S, double& rb, int& rsl, int* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     const int G = P.g.G;
     constexpr int NR = D == 3 ? 9 : 3;
@@ -635,7 +635,7 @@ ICPX_DEV bool coop_box(const double (&q)[D], const bool act, const int (&c0)[D],
 // (best, bslot) of the lanes in `walk`: running lexicographic minimum of (d2, cloud index), bslot < 0 = none yet.
 template <int D, bool TIES = false>
 ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w0)[D], const int (&w1)[D],
-                            const LdsView<D>& L, const GridView& P, double& best, int& bslot, bool* tie = nullptr) {
+                            const LdsView<D>& L, const GridView& P, double& best, int& bslot, int* tie = nullptr) {
     const int lane = threadIdx.x & 63;
     const int G = P.g.G;
     int first = 0, last = 0;
@@ -654,7 +654,7 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
         const int kb = P.cstart[__shfl(first, src)], ke = P.cstart[__shfl(last, src) + 1];
         double mb = __builtin_inf();
         int ms = -1;
-        bool lt = false;
+        int lt = 0;
         for (int j = kb + lane; j < ke; j += 64) {
             double df = L.t[0][j] - qq[0];
             double acc = df * df;
@@ -663,7 +663,7 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
                 df = L.t[d][j] - qq[d];
                 acc = acc + df * df;
             }
-            if (TIES) lt = lt || slot_tie<D>(true, acc, j, mb, ms, L);
+            if (TIES) lt |= slot_tie<D>(true, acc, j, mb, ms, L) ? 1 : 0;
             bool better = acc < mb;
             if (acc == mb && ms >= 0) better = P.tperm[j] < P.tperm[ms];
             mb = better ? acc : mb;
@@ -674,7 +674,7 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
         for (int o = 32; o >= 1; o >>= 1) {
             const double ob = __shfl_xor(mb, o);
             const int os = __shfl_xor(ms, o);
-            if (TIES) lt = lt || slot_tie<D>(os >= 0, ob, os, mb, ms, L);
+            if (TIES) lt |= slot_tie<D>(os >= 0, ob, os, mb, ms, L) ? 1 : 0;
             bool take = os >= 0 && (ms < 0 || ob < mb);
             const bool tie = os >= 0 && ms >= 0 && ob == mb && os != ms;
             if (__any(tie)) {
@@ -683,9 +683,9 @@ ICPX_DEV void coop_run_scan(const double (&q)[D], const bool walk, const int (&w
             mb = take ? ob : mb;
             ms = take ? os : ms;
         }
-        if (TIES) lt = __any(lt);
+        if (TIES) lt = __any(lt != 0) ? 1 : 0;
         if (lane == src && ms >= 0) {
-            if (TIES) *tie = *tie || lt || slot_tie<D>(true, mb, ms, best, bslot, L);
+            if (TIES) *tie |= lt | (slot_tie<D>(true, mb, ms, best, bslot, L) ? 1 : 0);
             bool take = bslot < 0 || mb < best;
             if (bslot >= 0 && mb == best && ms != bslot) take = P.tperm[ms] < P.tperm[bslot];
             best = take ? mb : best;
@@ -711,7 +711,7 @@ ICPX_DEV bool box_inside(const int (&a0)[D], const int (&a1)[D], const int (&b0)
 // query evaluates every target that close (its box is that of the bound), so it also sees the tie partners.
 template <int D, bool TIES = false>
 ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded, const LdsView<D>& L,
-                           const GridView& P, const CoopStage<D>& S, double& best, int& bslot, bool* tie = nullptr) {
+                           const GridView& P, const CoopStage<D>& S, double& best, int& bslot, int* tie = nullptr) {
     bool fin = P.g.bad == 0;
 #pragma unroll
     for (int d = 0; d < D; d++) fin = fin && (__builtin_fabs(q[d]) < 1e150);
@@ -786,7 +786,7 @@ ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded
                 stage = 3;
             } else {
                 // a local block: its minimum joins the bound; ties go to the block (it is the lexicographic minimum there)
-                if (TIES) *tie = *tie || slot_tie<D>(rsl >= 0, rb, rsl, best, bslot, L);
+                if (TIES) *tie |= slot_tie<D>(rsl >= 0, rb, rsl, best, bslot, L) ? 1 : 0;
                 const bool take = rsl >= 0 && !(rb > best);
                 best = take ? rb : best;
                 bslot = take ? rsl : bslot;

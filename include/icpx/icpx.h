@@ -22,12 +22,18 @@
  *     are not either); different handles may be used from different threads.
  *   - all arithmetic is IEEE f64, unfused (no FMA contraction), in the reference's operand order.
  *
- * Deterministic tie-break (documented rule): the nearest neighbour of a query is the
- * lexicographic minimum of (d2, target index) with d2 = sum over axes, in axis order, of
- * (target - query)^2.  This is bit-for-bit Trimmed::compute_matches
- * (lib/icp/impl/trimmed.cpp:95-109) and the brute force the reference's kd-tree test treats as
- * ground truth (tests/test.cpp:53-64); the reference kd-tree (include/algo/kdtree.h) can differ
- * from it only on exact ties of sqrt(d2).
+ * Deterministic tie-break (documented rules), d2 = sum over axes, in axis order, of (target - query)^2:
+ *   brute-force methods (Trimmed 2D, FeatureAware; icpx_nn): the nearest neighbour is the lexicographic
+ *     minimum of (d2, target index) — bit for bit Trimmed::compute_matches (lib/icp/impl/trimmed.cpp:95-109)
+ *     and the brute force the reference's kd-tree test treats as ground truth (tests/test.cpp:53-64);
+ *   kd-tree methods (Vanilla 2D, Vanilla3d, Trimmed3d; icpx_nn_kdtree): KdTree::search's answer
+ *     (include/algo/kdtree.h:132-154) — it compares sqrt(d2) with strict < and keeps the first node it
+ *     visits, so among the targets that share the minimal sqrt(d2) (coincident targets, symmetric
+ *     configurations, two d2 that round to one square root) the one that comes first in the
+ *     near-child-first pre-order of the median-split tree (kdtree.h:96-116) wins.  Where a split
+ *     subset holds equal coordinates the reference's tree is std::nth_element's choice
+ *     (implementation-defined); here such coordinates are ordered by index, and among coincident
+ *     targets the lowest index is returned.
  */
 #ifndef ICPX_H
 #define ICPX_H
@@ -258,6 +264,14 @@ int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double
  * mode: enum icpx_nn_mode.  device/stream as in icpx_params. */
 int icpx_nn(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
             int64_t* idx, double* d2, int mode, int device, void* stream);
+
+/* Stand-alone KdTree::search (include/algo/kdtree.h:79-89, 132-154) for n queries against the tree of
+ * `targets` (kdtree.h:42-52, 96-116): idx = the target the reference's tree walk returns, dist = its
+ * EUCLIDEAN distance (kdtree.h:126 takes the square root).  Same searches as icpx_nn; the queries whose
+ * minimum has a tie partner at the same sqrt(d2) are then resolved by the tree's visiting order (see the
+ * tie-break note at the top of this file).  mode / device / stream as icpx_nn. */
+int icpx_nn_kdtree(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
+                   int64_t* idx, double* dist, int mode, int device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -185,15 +185,18 @@ def check_case_3d(T, iters, case):
 
 
 
-def tie_clouds(dim, n_random, m_random, planted, seed):
-    """(queries, targets, planted query indices) with PLANTED kd-rule ties and, with overwhelming probability,
-    pairwise distinct coordinates on every axis — the data on which the reference's kd-tree is uniquely defined
-    and its first-visited pick differs from the (d2, index) rule about half of the time.  Two families per
-    planted query q (nothing else is nearer than its partners):
-      exact   two targets at q + v and q + v' with v' a signed permutation of v on a 2^-20 lattice: all the
-              arithmetic is exact, so the two d2 are bit-equal;
-      sqrt    two targets whose d2 differ by a few ulps and round to ONE square root (found by trial):
-              the case of ex_data/scan1, source 109."""
+def _seq_d2(x):
+    """sum of squares along the last axis in axis order, as the kernels and kdtree.h:124 accumulate it"""
+    x2 = x * x
+    s = x2[..., 0] + x2[..., 1]
+    return s + x2[..., 2] if x.shape[-1] == 3 else s
+
+
+import functools  # noqa: E402
+
+
+@functools.lru_cache(maxsize=None)
+def _tie_clouds(dim, n_random, m_random, planted, seed):
     rng = np.random.default_rng(seed)
     q = rng.uniform(-10, 10, (n_random, dim))
     t = rng.uniform(-10, 10, (m_random, dim))
@@ -211,22 +214,22 @@ def tie_clouds(dim, n_random, m_random, planted, seed):
             pq.append(c)
             pt += [c + v, c + v2]
         else:
-            for _ in range(2000):
-                v = rng.normal(size=dim)
-                v *= r / np.linalg.norm(v)
-                w = rng.normal(size=dim)
-                w *= r / np.linalg.norm(w)
-                # nudge w's length until the two squared distances are a few ulps apart with one square root
-                t1, t2 = c + v, c + w
-                d1 = (((t1 - c) ** 2).cumsum())[-1]
-                for _ in range(60):
-                    d2 = (((t2 - c) ** 2).cumsum())[-1]
-                    if d2 == d1 or np.sqrt(d2) == np.sqrt(d1):
-                        break
-                    t2 = c + (t2 - c) * np.sqrt(d1 / d2)
-                d2 = (((t2 - c) ** 2).cumsum())[-1]
-                if d2 != d1 and np.sqrt(d2) == np.sqrt(d1):
+            v = rng.normal(size=dim)
+            t1 = c + v * (r / np.linalg.norm(v))
+            d1 = _seq_d2(t1 - c)
+            t2 = None
+            for _ in range(8):
+                w = rng.normal(size=(2048, dim))
+                cand = c + w * (r / np.linalg.norm(w, axis=1))[:, None]
+                for _ in range(3):  # pull the candidates' squared distances to within a few ulps of d1
+                    cand = c + (cand - c) * np.sqrt(d1 / _seq_d2(cand - c))[:, None]
+                d2 = _seq_d2(cand - c)
+                ok = np.nonzero((d2 != d1) & (np.sqrt(d2) == np.sqrt(d1)))[0]
+                if len(ok):
+                    t2 = cand[ok[0]]
                     break
+            if t2 is None:  # (not seen in practice) fall back to an exact tie
+                t2 = c - (t1 - c)
             pq.append(c)
             pt += [t1, t2]
     pq, pt = np.array(pq).reshape(-1, dim), np.array(pt).reshape(-1, dim)
@@ -242,3 +245,16 @@ def tie_clouds(dim, n_random, m_random, planted, seed):
     qq = np.concatenate([q, pq])[order_q]
     planted_idx = np.nonzero(order_q >= len(q))[0]
     return np.ascontiguousarray(qq), np.ascontiguousarray(tt), planted_idx
+
+
+def tie_clouds(dim, n_random, m_random, planted, seed):
+    """(queries, targets, planted query indices) with PLANTED kd-rule ties and, with overwhelming probability,
+    pairwise distinct coordinates on every axis — the data on which the reference's kd-tree is uniquely defined
+    and its first-visited pick differs from the (d2, index) rule about half of the time.  Two families per
+    planted query q (nothing else is nearer than its partners):
+      exact   two targets at q + v and q + v' with v' a signed permutation of v on a 2^-20 lattice: all the
+              arithmetic is exact, so the two d2 are bit-equal;
+      sqrt    two targets whose d2 differ by a few ulps and round to ONE square root (found by trial):
+              the case of ex_data/scan1, source 109."""
+    qq, tt, pi = _tie_clouds(dim, n_random, m_random, planted, seed)
+    return qq.copy(), tt.copy(), pi.copy()

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import (BENCH_CRIT, PLY_CRIT, TEST_CRIT, check_case_2d, check_case_3d,
-                      reference_cases_2d, reference_cases_3d)
+                      reference_cases_2d, reference_cases_3d, tie_clouds)
 
 pytestmark = pytest.mark.gpu
 
@@ -98,26 +98,117 @@ def test_nn_empty_and_nonfinite(icp, ob):
         assert len(idx) == 0
 
 
-def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen):
-    """Against the REAL reference kd-tree (oracle/_ref when present, else its restatement):
-    indices may differ only where sqrt(d2) is bit-identical (the kd-tree compares sqrt(d2), kdtree.h:140,151, this
-    library d2 then the index: INTEGRATION.md section 4).  The number of such picks is pinned per data set: ONE query
-    of scan1 (source 109, targets 152 / 158), none elsewhere — the whole of the 7.5e-6 deviation of scan1 / vanilla
-    from the reference-order transform that test_scans_converge_bit_exact_and_golden allows for."""
-    total = 0
-    expect = {"scan1": 1, "scan2": 0, "scan3": 0}  # (queen: duplicated vertices, exact ties — reported only)
-    for name, (q, t) in [("scan1", scans[1]), ("scan2", scans[2]), ("scan3", scans[3]), ("queen", queen)]:
+@pytest.mark.parametrize("mode", ["auto", "brute", "grid", "bvh"])
+def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen, mode):
+    """icpx_nn_kdtree against the REAL reference kd-tree (oracle/_ref when present, else its restatement): ZERO
+    differing indices and bit-equal distances on scans 1-3 (source 109 of scan1 — two targets whose d2 are one ulp
+    apart and share a square root — included), on random clouds and on clouds with planted ties, all with distinct
+    coordinates (where the reference's tree is uniquely defined); through every search engine."""
+    m = {"auto": icp.NN_AUTO, "brute": icp.NN_BRUTE, "grid": icp.NN_GRID, "bvh": icp.NN_BVH}[mode]
+    rng = np.random.default_rng(23)
+    cases = [(f"scan{k}", *scans[k]) for k in (1, 2, 3)]
+    cases.append(("rand2", rng.uniform(-10, 10, (3000, 2)), rng.uniform(-10, 10, (2500, 2))))
+    cases.append(("rand3", rng.uniform(-10, 10, (5000, 3)), rng.uniform(-10, 10, (7001, 3))))
+    for dim in (2, 3):
+        q, t, _ = tie_clouds(dim, 2500, 4000, 300, 300 + dim)
+        cases.append((f"planted{dim}", q, t))
+    for name, q, t in cases:
         ki, kd = ob.ref_nn_kdtree(q, t) if ob.ref_lib() is not None else ob.nn_kdtree(q, t)
-        idx, d2 = icp.nearest_neighbors(q, t, icp.NN_AUTO)
-        assert np.array_equal(np.sqrt(d2), kd), name
-        diff = np.nonzero(idx != ki)[0]
-        for i in diff:
-            assert np.sqrt(((t[ki[i]] - q[i]) ** 2).sum()) == np.sqrt(d2[i])
-        assert name not in expect or len(diff) == expect[name], (name, diff)
-        if name == "scan1":
-            assert list(diff) == [109] and {int(idx[109]), int(ki[109])} == {152, 158}
-        total += len(diff)
-    print("kd-tree tie picks that differ from the (d2, index) rule:", total)
+        idx, dist = icp.nearest_neighbors_kdtree(q, t, m)
+        assert np.array_equal(dist, kd), (name, mode)
+        assert np.array_equal(idx, ki), (name, mode, np.nonzero(idx != ki)[0][:8])
+    # scan1, source 109: the tree's pick (158), not the (d2, index) minimum (152)
+    idx, _ = icp.nearest_neighbors_kdtree(*scans[1], m)
+    bi, _ = icp.nearest_neighbors(*scans[1], m)
+    assert idx[109] == 158 and bi[109] == 152
+    # coincident targets and lattices (the reference's tree is its nth_element's choice there): the canonical form
+    q, t = queen
+    ci, cd = ob.nn_kdcanon(q, t)
+    idx, dist = icp.nearest_neighbors_kdtree(q, t, m)
+    assert np.array_equal(idx, ci) and np.array_equal(dist, cd), mode
+    lat = rng.integers(0, 5, (900, 3)).astype(float)
+    ci, cd = ob.nn_kdcanon(lat[:400] + 0.5, lat)
+    idx, dist = icp.nearest_neighbors_kdtree(lat[:400] + 0.5, lat, m)
+    assert np.array_equal(idx, ci) and np.array_equal(dist, cd), mode
+    # no targets / non-finite points: the (d2, index) conventions
+    idx, dist = icp.nearest_neighbors_kdtree(np.zeros((3, 2)), np.zeros((0, 2)), m)
+    assert np.all(idx == 0) and np.all(np.isinf(dist))
+
+
+@pytest.mark.parametrize("path", ["fused", "large_auto", "large_grid", "large_bvh"])
+def test_kd_tie_rule_in_converge(icp, ob, path, knob):
+    """The kd-tree methods follow the reference tree's tie rule inside begin / iterate / converge: clouds with planted
+    ties (distinct coordinates), every iteration's neighbours, matches and transform against the oracle in canonical
+    form — whose correspondences equal the real kdtree.h's on such data (test_oracle).  fused: one workgroup per
+    pair (2D vanilla resolves in place; the 3D kernels stop at a tie and the take-over kernel goes on);
+    large_*: the multi-kernel path (stall, tree from the host, resolve kernel) with each correspondence engine."""
+    if path == "fused":
+        sizes, cfg_nn = (500, 900, 120), None
+    else:
+        sizes, cfg_nn = (5000, 6000, 200), path.split("_")[1]
+    # 2D vanilla: matches of begin (they never change, vanilla.cpp:80)
+    q, t, planted = tie_clouds(2, *sizes, 7)
+    cfg = icp.Config()
+    if cfg_nn:
+        cfg.set("nn", cfg_nn)
+    x = icp.ICP2.from_method("vanilla", cfg)
+    x.begin(q, t)
+    p, pair, c = x.get_matches_arrays()
+    ci, cd = ob.nn_kdcanon(q, t)
+    assert np.array_equal(pair, ci), np.nonzero(pair != ci)[0][:8]
+    assert np.array_equal(c, np.sqrt(cd))
+    if ob.ref_lib() is not None:
+        assert np.array_equal(pair, ob.ref_nn_kdtree(q, t)[0])
+    assert (ob.nn_brute(q, t)[0] != ci).sum() > 20  # the ties matter
+    crit = dict(max_iterations=20, transform_tol=(1e-6, 1e-6))
+    r = driver(icp, icp.ICP2, "vanilla", crit, cfg).converge(q, t)
+    ro = dev_oracle(ob, 2, "vanilla").converge(q, t, None, ob.make_criteria(**crit))
+    assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform) and r.cost == ro.cost
+    # both 3D methods: stepwise and whole converge
+    for method in ("vanilla", "trimmed"):
+        q, t, planted = tie_clouds(3, *sizes, 9)
+        cfg.set("max_distance", 0.5)
+        x = icp.ICP3.from_method(method, cfg)
+        o = dev_oracle(ob, 3, method, max_distance=0.5)
+        x.begin(q, t)
+        o.begin(q, t)
+        for it in range(3):
+            x.iterate()
+            o.iterate()
+            xi, xd = x.debug_neighbors()
+            oi, od = o.neighbors()
+            assert np.array_equal(xi, oi) and np.array_equal(xd, od), (method, it, np.nonzero(xi != oi)[0][:8])
+            assert np.array_equal(x.current_transform(), o.current_transform()), (method, it)
+        crit = dict(max_iterations=12, transform_tol=(1e-7, 1e-7))
+        r = driver(icp, icp.ICP3, method, crit, cfg).converge(q, t)
+        ro = o.converge(q, t, None, ob.make_criteria(**crit))
+        assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform), method
+
+
+def test_kd_tie_rule_in_batches(icp, ob):
+    """icpx_converge_batch (grid-pruned kernels detect, the take-over kernel resolves): pairs with planted ties next to
+    pairs without, both 3D methods and 2D vanilla, against the oracle in canonical form."""
+    from icp_amd import synth
+    for dim, method in ((3, "vanilla"), (3, "trimmed"), (2, "vanilla")):
+        srcs, dsts = [], []
+        for k in range(10):
+            if k % 3 == 0:
+                s, t, _, _ = synth.config5_pairs([100 + k], dim, 700)
+            else:
+                s, t, _ = tie_clouds(dim, 600, 800, 40, 30 + k)
+            srcs.append(s)
+            dsts.append(t)
+        so = np.concatenate([[0], np.cumsum([len(s) for s in srcs])])
+        to = np.concatenate([[0], np.cumsum([len(t) for t in dsts])])
+        crit = dict(max_iterations=12, transform_tol=(1e-7, 1e-7))
+        cfg = icp.Config()
+        cfg.set("max_distance", 0.5)
+        cost, its, T = icp.converge_batch(dim, method, np.concatenate(srcs), so, np.concatenate(dsts), to,
+                                          icp.make_criteria(**crit), cfg)
+        for k in range(10):
+            ro = dev_oracle(ob, dim, method, max_distance=0.5).converge(srcs[k], dsts[k], None, ob.make_criteria(**crit))
+            assert its[k] == ro.iteration_count and np.array_equal(T[k], ro.transform), (dim, method, k)
+            assert cost[k] == ro.cost
 
 
 # ------------------------------------------------------------------------------------------
@@ -145,10 +236,9 @@ def test_scans_converge_bit_exact_and_golden(icp, ob, scans, traces, method, k, 
     assert r.iteration_count == g["iterations"] and np.array_equal(r.transform, g["transform"])
     gr = traces[f"scan{k}/{method}/ref"]
     assert r.iteration_count == gr["iterations"]
-    tol = 1e-5 if (k == 1 and method == "vanilla") else TOL  # one kd-tree tie pick (see test_oracle)
-    assert np.abs(r.transform - gr["transform"]).max() < tol
-    # reference summation order with the canonical NN: always within 1e-6
-    rs = ob.OracleICP(2, method, nn_mode=ob.NN_BRUTE).converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
+    assert np.abs(r.transform - gr["transform"]).max() < TOL  # north_star, every (scan, method)
+    # reference summation order and the real kd-tree walk (ORC_NN_KDTREE): within 1e-6 too
+    rs = ob.OracleICP(2, method, nn_mode=ob.NN_KDTREE).converge(a, b, None, ob.make_criteria(**BENCH_CRIT))
     assert rs.iteration_count == r.iteration_count
     assert np.abs(rs.transform - r.transform).max() < TOL
     assert abs(rs.cost - r.cost) < 1e-12

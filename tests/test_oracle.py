@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import (BENCH_CRIT, GOLDEN, PLY_CRIT, TEST_CRIT, check_case_2d, check_case_3d,
-                      reference_cases_2d, reference_cases_3d)
+                      reference_cases_2d, reference_cases_3d, tie_clouds)
 
 
 def kat_points():
@@ -61,6 +61,60 @@ def test_kdtree_vs_brute_differ_only_on_sqrt_ties(ob, scans, queen):
         counts[name] = len(diff)
     # scan1 holds ONE sqrt collision: source point 109, targets 152 / 158, d2 one ulp apart
     assert counts["scan1"] == 1 and counts["scan2"] == 0 and counts["scan3"] == 0
+
+
+def test_canonical_kd_rule_equals_real_reference_kdtree(ob, scans, queen):
+    """ORC_NN_KDCANON — the rule the HIP kernels implement for the kd-tree methods — against the reference's own
+    include/algo/kdtree.h (oracle/_ref): identical indices and distances wherever the reference tree is uniquely
+    defined (distinct coordinates): scans 1-3 (scan1's sqrt collision at source 109 included), the reference's own
+    kd-tree test cloud, random clouds, and clouds with PLANTED ties (exact d2 ties between distinct targets and
+    pairs of d2 that round to one square root), on which the (d2, index) rule differs from the tree dozens of times."""
+    if ob.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (reference checkout absent)")
+    pts = kat_points()
+    cases = [("kat", pts, pts)] + [(f"scan{k}", *scans[k]) for k in (1, 2, 3)]
+    rng = np.random.default_rng(17)
+    cases.append(("rand2", rng.normal(size=(900, 2)), rng.normal(size=(1200, 2))))
+    cases.append(("rand3", rng.uniform(-3, 3, (1500, 3)), rng.uniform(-3, 3, (2500, 3))))
+    brute_differs = 0
+    for dim in (2, 3):
+        q, t, planted = tie_clouds(dim, 700, 1300, 150, 100 + dim)
+        for a in range(dim):
+            assert len(np.unique(t[:, a])) == len(t)  # the reference tree is uniquely defined
+        cases.append((f"planted{dim}", q, t))
+        brute_differs += int((ob.nn_brute(q, t)[0] != ob.ref_nn_kdtree(q, t)[0]).sum())
+    assert brute_differs > 40  # the planted ties do tell the two rules apart
+    for name, q, t in cases:
+        ri, rd = ob.ref_nn_kdtree(q, t)
+        ci, cd = ob.nn_kdcanon(q, t)
+        assert np.array_equal(ci, ri), (name, np.nonzero(ci != ri)[0][:5])
+        assert np.array_equal(cd, rd), name
+    # queen.ply: 1 956 duplicated vertices.  Which of coincident targets the reference returns is its nth_element's
+    # choice; the canonical rule returns the lowest index among them: same coordinates, same distances
+    q, t = queen
+    ri, rd = ob.ref_nn_kdtree(q, t)
+    ci, cd = ob.nn_kdcanon(q, t)
+    assert np.array_equal(cd, rd) and np.array_equal(t[ci], t[ri])
+
+
+def test_canonical_kd_rule_two_formulations(ob, scans, queen):
+    """The tree walk (kdtree.h:132-154 on the canonical tree) and the brute-force formulation of the same rule (minimum,
+    tied set by sqrt(d2), smallest pre-order key, lowest coincident index — what the kernels' tie resolution
+    computes): identical answers, also where ties abound (lattices, duplicated vertices, non-finite points)."""
+    rng = np.random.default_rng(5)
+    cases = [scans[1], (queen[0][:1500], queen[1])]
+    cases.append((rng.integers(0, 6, (400, 2)).astype(float), rng.integers(0, 6, (900, 2)).astype(float)))
+    cases.append((rng.integers(0, 4, (300, 3)).astype(float) + 0.5, rng.integers(0, 4, (1100, 3)).astype(float)))
+    for dim in (2, 3):
+        q, t, _ = tie_clouds(dim, 300, 700, 80, 200 + dim)
+        cases.append((q, t))
+    cases.append((np.array([[1.0, 2.0, 3.0]]), np.array([[4.0, 5.0, 6.0]])))
+    for q, t in cases:
+        wi, wd = ob.nn_kdcanon(q, t)
+        ki, kd = ob.nn_kdcanon(q, t, by_key=True)
+        assert np.array_equal(wi, ki) and np.array_equal(wd, kd)
+        bi, bd2 = ob.nn_brute(q, t)
+        assert np.array_equal(wd, np.sqrt(bd2))  # the distance is the minimum's under either rule
 
 
 def test_brute_lowest_index_on_duplicates(ob):
@@ -218,24 +272,15 @@ def test_golden_traces_reproduce(ob, scans, queen, traces):
 
 
 def test_reference_order_and_device_order_agree_to_1e6(ob, scans, queen, traces):
-    """north_star tolerance: final transforms within 1e-6 rad / 1e-6 m between the reference-order
-    restatement (kd-tree, sequential sums) and the device order ((d2,index) NN, TREE64 sums).
-    Where the kd-tree's tie pick differs from the canonical rule (scan1 vanilla, one sqrt
-    collision) the comparison is made against the canonical NN in reference summation order, and
-    the tie's effect is bounded separately."""
+    """north_star tolerance: final transforms within 1e-6 rad / 1e-6 m between the reference-order restatement
+    (real kd-tree walk, sequential sums) and the device order (the kd rule in canonical form, TREE64 sums) — for
+    every data set and method, scan1 / vanilla with its sqrt collision included."""
     for key, g in traces.items():
         if not key.endswith("/ref"):
             continue
         d = traces[key[:-3] + "dev"]
         assert g["iterations"] == d["iterations"], key
-        if key == "scan1/vanilla/ref":
-            a, b = scans[1]
-            r = ob.OracleICP(2, "vanilla", nn_mode=ob.NN_BRUTE, sum_mode=ob.SUM_SEQUENTIAL).converge(
-                a, b, None, ob.make_criteria(**BENCH_CRIT))
-            assert np.abs(r.transform - d["transform"]).max() < 1e-12
-            assert np.abs(g["transform"] - d["transform"]).max() < 1e-5  # one tie among 953 pairs
-        else:
-            assert np.abs(g["transform"] - d["transform"]).max() < 1e-6, key
+        assert np.abs(g["transform"] - d["transform"]).max() < 1e-6, key
 
 
 def test_quirks(ob, scans):

@@ -68,6 +68,7 @@ for method in ("vanilla", "trimmed"):
         check(f"B {method} {seed} converge", r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform),
               f"{r.iteration_count} {ro.iteration_count}")
 
+SKIP_ABC = os.environ.get('KD_SKIP_ABC') == '1'
 # C: 3D batches (pruned kernels + take-over); some pairs with ties, some without
 from icp_amd import synth  # noqa: E402
 
@@ -91,6 +92,52 @@ for method in ("vanilla", "trimmed"):
         ro = ob.OracleICP(3, method, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64, max_distance=0.5).converge(
             srcs[k], dsts[k], None, ob.make_criteria(**crit))
         check(f"C {method} pair {k}", its[k] == ro.iteration_count and np.array_equal(T[k], ro.transform), f"{its[k]} {ro.iteration_count}")
+
+# D: the stand-alone kd-tree query, every engine
+for dim in (2, 3):
+    q, t, pi = tie_clouds(dim, 3000, 5000, 300, 40 + dim)
+    ri, rd = ob.ref_nn_kdtree(q, t) if ob.ref_lib() is not None else ob.nn_kdcanon(q, t)
+    for mode, name in ((icp_amd.NN_AUTO, "auto"), (icp_amd.NN_BRUTE, "brute"), (icp_amd.NN_GRID, "grid"), (icp_amd.NN_BVH, "bvh")):
+        idx, dist = icp_amd.nearest_neighbors_kdtree(q, t, mode)
+        check(f"D {dim}D {name} == real kdtree.h", np.array_equal(idx, ri) and np.array_equal(dist, rd), f"diff {(idx != ri).sum()}")
+    lat = np.random.default_rng(1).integers(0, 5, (800, dim)).astype(float)
+    ci, cd = ob.nn_kdcanon(lat[:300] + 0.5, lat)
+    for mode, name in ((icp_amd.NN_BRUTE, "brute"), (icp_amd.NN_GRID, "grid"), (icp_amd.NN_BVH, "bvh")):
+        idx, dist = icp_amd.nearest_neighbors_kdtree(lat[:300] + 0.5, lat, mode)
+        check(f"D {dim}D lattice {name} == canon", np.array_equal(idx, ci) and np.array_equal(dist, cd), f"diff {(idx != ci).sum()}")
+
+# E: large path (multi-kernel): 2D vanilla and 3D, tiled / grid / bvh
+for nn in ("auto", "grid", "bvh"):
+    q, t, pi = tie_clouds(2, 5000, 6000, 200, 50)
+    cfg = icp_amd.Config()
+    cfg.set("nn", nn)
+    x = icp_amd.ICP2.from_method("vanilla", cfg)
+    x.begin(q, t)
+    p, pair, c = x.get_matches_arrays()
+    ci, cd = ob.nn_kdcanon(q, t)
+    check(f"E 2D vanilla large {nn} begin", np.array_equal(pair, ci), f"diff {(pair != ci).sum()}")
+    for method in ("vanilla", "trimmed"):
+        q, t, pi = tie_clouds(3, 5000, 6000, 200, 60)
+        cfg.set("max_distance", 0.5)
+        x = icp_amd.ICP3.from_method(method, cfg)
+        o = ob.OracleICP(3, method, nn_mode=ob.NN_KDCANON, sum_mode=ob.SUM_TREE64, max_distance=0.5)
+        x.begin(q, t)
+        o.begin(q, t)
+        for it in range(3):
+            x.iterate()
+            o.iterate()
+            xi, xd = x.debug_neighbors()
+            oi, od = o.neighbors()
+            check(f"E 3D {method} {nn} it{it}", np.array_equal(xi, oi) and np.array_equal(x.current_transform(), o.current_transform()),
+                  f"diff {(xi != oi).sum()}")
+        crit = dict(max_iterations=10, transform_tol=(1e-7, 1e-7))
+        d = icp_amd.ICPDriver(icp_amd.ICP3.from_method(method, cfg))
+        d.set_max_iterations(10)
+        d.set_transform_tolerance(1e-7, 1e-7)
+        r = d.converge(q, t)
+        ro = o.converge(q, t, None, ob.make_criteria(**crit))
+        check(f"E 3D {method} {nn} converge", r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform),
+              f"{r.iteration_count} {ro.iteration_count}")
 
 print("FAILS", fails)
 sys.exit(1 if fails else 0)
