@@ -51,7 +51,22 @@ def main():
                          "ranks; default 0 = weak scaling, 512 + 512 pairs per GPU")
     ap.add_argument("--verify-pairs", type=int, default=2, help="pairs per kind checked against the oracle after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=512, help="pairs per dim timed on the CPU")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing (gloo, no kernels): launch, shard ranges, result gather")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU) BEFORE anything touches a
+    # GPU, relay rank 0's JSON line and leave with the launcher's exit code.  Under torch.distributed.run (the
+    # driver's N > 1 launch) WORLD_SIZE is set and this process is one of the ranks.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"error: --gpus {args.gpus} but WORLD_SIZE is {world_env}: start it as `python bench.py --gpus N` "
+              "or under torch.distributed.run with --nproc-per-node N", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_ranks:
+        sys.exit(dry_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -62,12 +77,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        rccl_ranks = dist.get_world_size()
 
     icp_amd._lib.check(icp_amd._lib.load().icpx_init(local_rank))
 
@@ -141,6 +156,7 @@ def main():
             "value": total_q / (elapsed / args.steps),
             "unit": "queries/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,   # dist.get_world_size() after the NCCL (= RCCL) initialisation
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -168,12 +184,66 @@ def main():
         }
         if not args.no_extras and world == 1:
             line["extras"] = extras(torch, icp_amd, synth, dev, local_rank, torch.cuda.current_stream(dev).cuda_stream)
+            if not args.pairs_total:
+                line["extras"].update(extras_config5(torch, icp_amd, workload, sh, local_rank))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(s2, t2, off2, s3, t3, off3, args.cpu_sample)
             line["cpu_baseline_all_cores"] = cpu_baseline_threads(s2, t2, off2, s3, t3, off3, args.cpu_sample)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_ranks(n: int) -> int:
+    """One process per GPU through torch.distributed.run, as the driver starts N > 1 runs; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_ranks(args) -> int:
+    """--dry-ranks: what the N ranks do around the kernels, on the CPU over gloo — shard ranges of the config-5
+    batch, a fake result table per rank (row = pair id), the same gather bench.py's step() performs, one JSON line
+    from rank 0.  No GPU, no HIP library."""
+    import torch
+    import torch.distributed as dist
+    from icp_amd import shard
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    total2 = total3 = (args.pairs_total // 2) if args.pairs_total else 0
+    if not args.pairs_total:
+        total2, total3 = PAIRS_2D * world, PAIRS_3D * world
+    rows = []
+    for gi, g in enumerate((total2, total3)):
+        lo, hi = shard.shard_range(g, rank, world)
+        rows += [[gi, p] + [0.0] * 16 for p in range(lo, hi)]
+    local = torch.tensor(rows, dtype=torch.float64).reshape(-1, 18)
+    scratch = {}
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        table = shard.gather_states(local, total2 + total3, rank, world, counts=(total2, total3), scratch=scratch)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = table.shape[0] == total2 + total3
+    got = sorted((int(a), int(b)) for a, b in table[:, :2].tolist())
+    ok = ok and got == sorted([(0, p) for p in range(total2)] + [(1, p) for p in range(total3)])
+    ranks = dist.get_world_size() if world > 1 else 1
+    if rank == 0:
+        print(json.dumps({"dry_ranks": True, "n_gpus": args.gpus, "ranks": ranks, "backend": "gloo",
+                          "pairs_total": total2 + total3, "pairs_per_rank": local.shape[0], "gather_ok": bool(ok),
+                          "gather_ms": dt / max(1, args.steps) * 1e3}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 UNFUSED_F64_PEAK_TFLOPS = FP64_PEAK_TFLOPS / 2   # one f64 flop per lane per VALU f64 issue slot (no FMA pairing)
@@ -395,18 +465,67 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
     return ex
 
 
+def extras_config5(torch, icp_amd, workload, sh, local_rank):
+    """Config 5 beyond the headline shard, on this one GPU: the WHOLE 8192-pair batch in one step (the strong-scaling
+    figure at N = 1), and the two method / dimension combinations the headline step leaves out (config 5 names
+    "vanilla and trimmed" for both dimensions): 512 2D vanilla pairs and 512 3D trimmed pairs."""
+    ex = {}
+    from icp_amd import api
+    crit = sh.crit
+    dev = sh.dev
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    out = torch.zeros((max(sh.p2, sh.p3), 18), dtype=torch.float64, device=dev)
+    if sh.p2:
+        ms = timed(lambda: api.converge_batch(2, "vanilla", sh.d_s2, sh.off2, sh.d_t2, sh.off2, crit,
+                                              out_states=out[:sh.p2], device=local_rank, stream=cur))
+        ex["c5_2d_vanilla_batch_ms"] = ms
+        ex["c5_2d_vanilla_pairs_per_s"] = sh.p2 / (ms * 1e-3)
+    if sh.p3:
+        cfg = icp_amd.Config()
+        ms = timed(lambda: api.converge_batch(3, "trimmed", sh.d_s3, sh.off3, sh.d_t3, sh.off3, crit, cfg,
+                                              out_states=out[:sh.p3], device=local_rank, stream=cur))
+        ex["c5_3d_trimmed_batch_ms"] = ms
+        ex["c5_3d_trimmed_pairs_per_s"] = sh.p3 / (ms * 1e-3)
+        it = out[:sh.p3].cpu().numpy().reshape(-1).view(workload.STATE_DT)["it"]
+        ex["c5_3d_trimmed_mean_iterations"] = float(it.mean())
+    del out
+    # the whole config-5 batch (4096 + 4096 pairs, ~1 GB of clouds) on this GPU: strong scaling at N = 1
+    full = workload.Config5Shard(torch, 0, 1, 4096, 4096, local_rank)
+    ms = timed(lambda: full.step(), reps=3)
+    st2, st3 = full.states()
+    q = int(((st2["it"].astype(np.int64) + 1) * N_2D).sum()) + int((st3["it"].astype(np.int64) * N_3D).sum())
+    ex["c5_full_8192_ms"] = ms
+    ex["c5_full_8192_pairs_per_s"] = 8192 / (ms * 1e-3)
+    ex["c5_full_8192_queries_per_s"] = q / (ms * 1e-3)
+    del full
+    return ex
+
+
 def cpu_baseline(s2, t2, off2, s3, t3, off3, sample):
     """The oracle in reference order on one host core, on the first `sample` pairs of each kind."""
     from oracle import binding as ob
     crit = ob.make_criteria(max_iterations=MAX_ITER, transform_tol=TOL)
     k2, k3 = min(sample, PAIRS_2D), min(sample, PAIRS_3D)
     queries = 0
+    # the kd-tree legs run through the reference's OWN include/algo/kdtree.h when oracle/_ref/liboracle_ref.so was
+    # built from the reference checkout (oracle/Makefile); the restated tree otherwise
+    ref_tree = ob.lib_ref_tree() is not None
     t0 = time.perf_counter()
     o2 = ob.OracleICP(2, "trimmed")  # brute-force NN + std::sort, as trimmed.cpp
     for p in range(k2):
         r = o2.converge(s2[off2[p]:off2[p + 1]], t2[off2[p]:off2[p + 1]], None, crit)
         queries += (r.iteration_count + 1) * N_2D
-    o3 = ob.OracleICP(3, "vanilla")  # kd-tree NN, as vanilla_3d.cpp
+    o3 = ob.OracleICP(3, "vanilla", reference_tree=ref_tree)  # kd-tree NN, as vanilla_3d.cpp:30-45,75-80
     for p in range(k3):
         r = o3.converge(s3[off3[p]:off3[p + 1]], t3[off3[p]:off3[p + 1]], None, crit)
         queries += r.iteration_count * N_3D
@@ -416,10 +535,13 @@ def cpu_baseline(s2, t2, off2, s3, t3, off3, sample):
         "unit": "queries/s",
         "pairs_per_s": (k2 + k3) / dt,
         "cores": 1,
-        "kind": "port",
+        "kind": "reference" if ref_tree else "port",
         "sample": f"first {k2} 2D pairs + first {k3} 3D pairs of rank 0's shard, {dt:.1f} s of CPU time; "
-                  "oracle in reference order (brute-force NN + std::sort for trimmed ICP2, kd-tree NN for "
-                  "vanilla ICP3, sequential sums), g++ -O3 -DNDEBUG",
+                  + ("kd-tree build and search of vanilla ICP3 = the reference's own include/algo/kdtree.h compiled "
+                     "from its sources (oracle/_ref); " if ref_tree else "kd-tree restated (oracle/_ref not built); ")
+                  + "everything that needs Eigen in the reference (brute-force NN + std::sort of trimmed ICP2, sums, "
+                    "Kabsch SVD, driver) is the oracle's restatement in reference order — Eigen is absent here, the "
+                    "reference's method classes cannot be built; g++ -O3 -DNDEBUG",
     }
 
 
@@ -437,9 +559,11 @@ def cpu_baseline_threads(s2, t2, off2, s3, t3, off3, sample):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)), 64))
 
+    ref_tree = ob.lib_ref_tree() is not None
+
     def work(w):
         q = 0
-        o2, o3 = ob.OracleICP(2, "trimmed"), ob.OracleICP(3, "vanilla")
+        o2, o3 = ob.OracleICP(2, "trimmed"), ob.OracleICP(3, "vanilla", reference_tree=ref_tree)
         for p in range(w, k3, cores):  # the expensive pairs first
             r = o3.converge(s3[off3[p]:off3[p + 1]], t3[off3[p]:off3[p + 1]], None, crit)
             q += r.iteration_count * N_3D
@@ -457,7 +581,7 @@ def cpu_baseline_threads(s2, t2, off2, s3, t3, off3, sample):
         "unit": "queries/s",
         "pairs_per_s": (k2 + k3) / dt,
         "cores": cores,
-        "kind": "port",
+        "kind": "reference" if ref_tree else "port",
         "sample": f"the same {k2} + {k3} pairs spread over {cores} worker threads, {dt:.1f} s wall",
     }
 

@@ -56,8 +56,21 @@ def build(force: bool = False) -> None:
 
 _lib = None
 _ref = None
+_lib_ref_tree = None
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
+
+
+def lib_ref_tree():
+    """oracle/_ref/liboracle_ref.so: the oracle with NN_KDTREE served by the reference's own kdtree.h (compiled from
+    where it lies).  None when not built."""
+    global _lib_ref_tree
+    if _lib_ref_tree is None:
+        path = os.path.join(_HERE, "_ref", "liboracle_ref.so")
+        if not os.path.exists(path):
+            return None
+        _lib_ref_tree = _bind(C.CDLL(path))
+    return _lib_ref_tree
 
 
 def lib():
@@ -66,29 +79,32 @@ def lib():
         path = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
-        L = C.CDLL(path)
-        L.orc_nn_brute.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp]
-        L.orc_nn_kdtree.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp]
-        L.orc_nn_kdcanon.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp, C.c_int, C.POINTER(C.c_int32)]
-        L.orc_jacobi_svd.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
-        L.orc_kabsch.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
-        L.orc_sum.argtypes = [_dp, C.c_int64, C.c_int]
-        L.orc_sum.restype = C.c_double
-        L.orc_create.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]
-        L.orc_create.restype = C.c_void_p
-        L.orc_destroy.argtypes = [C.c_void_p]
-        L.orc_begin.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, _dp]
-        L.orc_iterate.argtypes = [C.c_void_p]
-        L.orc_cost.argtypes = [C.c_void_p]
-        L.orc_cost.restype = C.c_double
-        L.orc_transform.argtypes = [C.c_void_p, _dp]
-        L.orc_matches.argtypes = [C.c_void_p, _ip, _ip, _dp]
-        L.orc_neighbors.argtypes = [C.c_void_p, _ip, _dp]
-        L.orc_current_cloud.argtypes = [C.c_void_p, _dp]
-        L.orc_converge.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, _dp,
-                                   C.POINTER(Criteria), C.POINTER(State), C.c_int64, _dp, _dp]
-        _lib = L
+        _lib = _bind(C.CDLL(path))
     return _lib
+
+
+def _bind(L):
+    L.orc_nn_brute.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp]
+    L.orc_nn_kdtree.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp]
+    L.orc_nn_kdcanon.argtypes = [C.c_int, _dp, C.c_int64, _dp, C.c_int64, _ip, _dp, C.c_int, C.POINTER(C.c_int32)]
+    L.orc_jacobi_svd.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+    L.orc_kabsch.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+    L.orc_sum.argtypes = [_dp, C.c_int64, C.c_int]
+    L.orc_sum.restype = C.c_double
+    L.orc_create.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]
+    L.orc_create.restype = C.c_void_p
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_begin.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, _dp]
+    L.orc_iterate.argtypes = [C.c_void_p]
+    L.orc_cost.argtypes = [C.c_void_p]
+    L.orc_cost.restype = C.c_double
+    L.orc_transform.argtypes = [C.c_void_p, _dp]
+    L.orc_matches.argtypes = [C.c_void_p, _ip, _ip, _dp]
+    L.orc_neighbors.argtypes = [C.c_void_p, _ip, _dp]
+    L.orc_current_cloud.argtypes = [C.c_void_p, _dp]
+    L.orc_converge.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, _dp,
+                               C.POINTER(Criteria), C.POINTER(State), C.c_int64, _dp, _dp]
+    return L
 
 
 def ref_lib():
@@ -232,17 +248,20 @@ class OracleICP:
     """Mirror of icp::ICP<Dim> (icp.h) + ICPDriver::converge (driver.h) on the CPU oracle."""
 
     def __init__(self, dim, method, overlap_rate=0.9, max_distance=1.0, nn_mode=NN_KDTREE,
-                 sum_mode=SUM_SEQUENTIAL, feature_weight=0.7, symmetric_neighbors=10, flags=0):
+                 sum_mode=SUM_SEQUENTIAL, feature_weight=0.7, symmetric_neighbors=10, flags=0, reference_tree=False):
+        # reference_tree: NN_KDTREE through the reference's own kdtree.h (oracle/_ref/liboracle_ref.so)
+        self._L = lib_ref_tree() if reference_tree else lib()
+        assert self._L is not None, "oracle/_ref/liboracle_ref.so is not built"
         self.dim = dim
         self.method = {"vanilla": VANILLA, "trimmed": TRIMMED, "feature_aware": FEATURE_AWARE}.get(method, method)
         p = Params(overlap_rate, max_distance, nn_mode, sum_mode, feature_weight, symmetric_neighbors, flags)
-        self._h = lib().orc_create(dim, self.method, C.byref(p))
+        self._h = self._L.orc_create(dim, self.method, C.byref(p))
         assert self._h
         self.n = 0
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+            self._L.orc_destroy(self._h)
             self._h = None
 
     def _guess(self, guess):
@@ -254,36 +273,36 @@ class OracleICP:
         src, dst = _cloud(src, self.dim), _cloud(dst, self.dim)
         g = self._guess(guess)
         self.n = len(src)
-        lib().orc_begin(self._h, _d(src), len(src), _d(dst), len(dst), g.ctypes.data_as(_dp))
+        self._L.orc_begin(self._h, _d(src), len(src), _d(dst), len(dst), g.ctypes.data_as(_dp))
 
     def iterate(self):
-        lib().orc_iterate(self._h)
+        self._L.orc_iterate(self._h)
 
     def calculate_cost(self):
-        return lib().orc_cost(self._h)
+        return self._L.orc_cost(self._h)
 
     def current_transform(self):
         d1 = self.dim + 1
         out = np.zeros((d1, d1), order="F")
-        lib().orc_transform(self._h, out.ctypes.data_as(_dp))
+        self._L.orc_transform(self._h, out.ctypes.data_as(_dp))
         return np.array(out)
 
     def get_matches(self):
         p = np.zeros(self.n, np.int64)
         q = np.zeros(self.n, np.int64)
         c = np.zeros(self.n, np.float64)
-        lib().orc_matches(self._h, _i(p), _i(q), _d(c))
+        self._L.orc_matches(self._h, _i(p), _i(q), _d(c))
         return p, q, c
 
     def neighbors(self):
         idx = np.zeros(self.n, np.int64)
         dist = np.zeros(self.n, np.float64)
-        lib().orc_neighbors(self._h, _i(idx), _d(dist))
+        self._L.orc_neighbors(self._h, _i(idx), _d(dist))
         return idx, dist
 
     def current_cloud(self):
         out = np.zeros((self.n, self.dim))
-        lib().orc_current_cloud(self._h, _d(out))
+        self._L.orc_current_cloud(self._h, _d(out))
         return out
 
     def converge(self, src, dst, guess=None, criteria=None, trace_cap=0):
@@ -294,7 +313,7 @@ class OracleICP:
         st = State()
         tc = np.zeros(max(trace_cap, 1))
         tt = np.zeros((max(trace_cap, 1), d1 * d1))
-        lib().orc_converge(self._h, _d(src), len(src), _d(dst), len(dst), g.ctypes.data_as(_dp),
+        self._L.orc_converge(self._h, _d(src), len(src), _d(dst), len(dst), g.ctypes.data_as(_dp),
                            C.byref(criteria), C.byref(st), trace_cap, _d(tc), _d(tt))
         T = np.array(st.transform[: d1 * d1]).reshape(d1, d1, order="F")
         k = min(int(st.iteration_count), trace_cap)

@@ -104,6 +104,37 @@ void nn_brute(const double* q, int64_t n, const double* t, int64_t m, int64_t* i
     }
 }
 
+#ifdef ORC_REFERENCE_KDTREE
+}  // namespace
+// oracle/_ref/liboracle_ref.so (oracle/Makefile): the SAME oracle with ORC_NN_KDTREE served by the reference's own
+// include/algo/kdtree.h, compiled from where it lies (-I$(REF)/include) — bench.py's cpu_baseline ("kind":
+// "reference" for the kd-tree legs).  This wrapper only adapts the point type.
+#include "algo/kdtree.h"
+namespace {
+template <int D>
+class KdTree {
+public:
+    void build(const double* pts, int64_t m) {
+        std::vector<Pt> p(static_cast<size_t>(m));
+        for (int64_t j = 0; j < m; j++)
+            for (int k = 0; k < D; k++) p[j].v[k] = pts[j * D + k];
+        kt_.build(p, D);
+    }
+    int search(const double* query, double* min_dist) const {
+        Pt q;
+        for (int k = 0; k < D; k++) q.v[k] = query[k];
+        return kt_.search(q, min_dist);
+    }
+
+private:
+    struct Pt {
+        double v[D];
+        double operator[](int i) const { return v[i]; }
+        int size() const { return D; }
+    };
+    icp::KdTree<Pt> kt_;
+};
+#else
 // kdtree.h restated.  Nodes are kept in a flat vector instead of unique_ptrs; the build order,
 // split rule and traversal are the reference's.
 template <int D>
@@ -180,6 +211,8 @@ private:
     std::vector<Node> nodes_;
     int root_ = -1;
 };
+
+#endif  // ORC_REFERENCE_KDTREE
 
 // ---------------------------------------------------------------------------------------------
 // The kd-tree RULE, canonical form (ORC_NN_KDCANON) — what the HIP kernels are held to for the

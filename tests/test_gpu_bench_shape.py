@@ -54,3 +54,29 @@ def test_benched_shard_parity(ob, knob):
         other = sh.out.cpu().numpy()
         bad = np.nonzero((other != first).any(axis=1))[0]
         assert len(bad) == 0, (name, bad[:10])
+
+
+def test_whole_config5_batch_once(ob):
+    """All of config 5 (4096 2D + 4096 3D pairs, ~1 GB of clouds) in ONE step on one GPU — the strong-scaling
+    figure bench.py reports as extras.c5_full_8192_ms.  16 sampled pairs bit for bit against the oracle; the first
+    512 pairs of either kind are rank 0's shard at N = 8 and must equal that shard run on its own."""
+    import torch
+
+    import icp_amd
+    from icp_amd import workload
+    import bench_check
+
+    icp_amd._lib.check(icp_amd._lib.load().icpx_init(0))
+    full = workload.Config5Shard(torch, 0, 1, 4096, 4096, 0)
+    assert (full.p2, full.p3) == (4096, 4096)
+    full.step()
+    torch.cuda.synchronize()
+    f2, f3 = full.states()
+    assert f2["it"].min() >= 1 and f3["it"].min() >= 1
+    assert bench_check.verify_sample(ob, full, 8) == 16
+    sh = workload.Config5Shard(torch, 0, 8, 4096, 4096, 0)
+    sh.step()
+    torch.cuda.synchronize()
+    s2, s3 = sh.states()
+    assert np.array_equal(f2[:512].view(np.uint8), s2.view(np.uint8))
+    assert np.array_equal(f3[:512].view(np.uint8), s3.view(np.uint8))

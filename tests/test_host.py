@@ -187,6 +187,25 @@ dist.destroy_process_group()
     assert "OK" in out.stdout
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (before
+    anything touches a GPU); --dry-ranks runs the rank plumbing on the CPU over gloo (shard ranges, result gather)
+    with no kernels.  A WORLD_SIZE that disagrees with --gpus is an error, not a warning."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "--steps", "2"],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = lines[0]
+    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["gather_ok"]
+    assert line["pairs_total"] == 2048 and line["pairs_per_rank"] == 1024   # weak scaling: 512 + 512 per rank
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks"],
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="3"), timeout=60)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
 def test_batch_rejects_criteria_that_never_terminate():
     """the converge loop runs inside one kernel, so criteria under which it cannot end are an
     argument error (checked before any device is touched, hence testable here)."""
