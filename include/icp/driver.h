@@ -98,22 +98,51 @@ namespace icp {
         }
 
         static double rotation_angle(const RBTransform<Dim>& cur, const RBTransform<Dim>& last) {
-            // |angle| of R_cur * R_last^T (driver.h:196-210)
+            // angle of R_cur * R_last^T (driver.h:196-210): Rotation2Dd(...).smallestAngle() in 2D, AngleAxisd(...).angle()
+            // in 3D, which goes through a quaternion — the same operations, in the same order, as the device code
+            // (icp_amd/csrc/icpx_math.h rotation_angle), so a host-side subclass stops at the same iteration
             const double* c = cur.matrix().data();
             const double* l = last.matrix().data();
             constexpr int L = Dim + 1;
-            double m[3][3] = {{0}};
-            for (int i = 0; i < Dim; i++)
-                for (int j = 0; j < Dim; j++)
-                    for (int k = 0; k < Dim; k++) m[i][j] += c[k * L + i] * l[k * L + j];
+            constexpr double kPi = 3.141592653589793238462643383279502884;
             if constexpr (Dim == Dimension::TwoD) {
-                return std::atan2(m[1][0], m[0][0]);
+                double m00 = c[0 * L + 0] * l[0 * L + 0] + c[1 * L + 0] * l[1 * L + 0];
+                double m10 = c[0 * L + 1] * l[0 * L + 0] + c[1 * L + 1] * l[1 * L + 0];
+                double a = std::fmod(std::atan2(m10, m00), 2.0 * kPi);
+                if (a > kPi) a -= 2.0 * kPi;
+                else if (a < -kPi) a += 2.0 * kPi;
+                return a;
             } else {
-                double tr = m[0][0] + m[1][1] + m[2][2];
-                double cs = (tr - 1.0) / 2.0;
-                double sx = m[2][1] - m[1][2], sy = m[0][2] - m[2][0], sz = m[1][0] - m[0][1];
-                double sn = std::sqrt(sx * sx + sy * sy + sz * sz) / 2.0;
-                return std::atan2(sn, cs);
+                double m[3][3];
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) {
+                        double s = c[0 * L + i] * l[0 * L + j];
+                        for (int k = 1; k < 3; k++) s += c[k * L + i] * l[k * L + j];
+                        m[i][j] = s;
+                    }
+                double q[4];  // x, y, z, w
+                double t = m[0][0] + m[1][1] + m[2][2];
+                if (t > 0.0) {
+                    t = std::sqrt(t + 1.0);
+                    q[3] = 0.5 * t;
+                    t = 0.5 / t;
+                    q[0] = (m[2][1] - m[1][2]) * t;
+                    q[1] = (m[0][2] - m[2][0]) * t;
+                    q[2] = (m[1][0] - m[0][1]) * t;
+                } else {
+                    int i = 0;
+                    if (m[1][1] > m[0][0]) i = 1;
+                    if (m[2][2] > m[i][i]) i = 2;
+                    const int j = (i + 1) % 3, k = (j + 1) % 3;
+                    t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+                    q[i] = 0.5 * t;
+                    t = 0.5 / t;
+                    q[3] = (m[k][j] - m[j][k]) * t;
+                    q[j] = (m[j][i] + m[i][j]) * t;
+                    q[k] = (m[k][i] + m[i][k]) * t;
+                }
+                const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                return nrm != 0.0 ? 2.0 * std::atan2(nrm, std::abs(q[3])) : 0.0;
             }
         }
 

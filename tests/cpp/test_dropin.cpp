@@ -269,6 +269,58 @@ public:
     }
 };
 
+// A 3D consumer-written instance whose k-th iteration turns the transform to a given angle about z: exercises the host
+// loop's transform tolerance (driver.h:196-210), i.e. the quaternion angle — both branches of the matrix -> quaternion
+// conversion (trace > 0 and trace <= 0).
+class SpinAboutZ final : public icp::ICP3 {
+public:
+    std::vector<double> angles;
+    size_t k = 0;
+
+protected:
+    void setup() override {
+        k = 0;
+        for (icp::Index i = 0; i < a.cols(); i++) matches[static_cast<size_t>(i)] = Match{i, i, 1.0};
+    }
+
+public:
+    void iterate() override {
+        const double th = angles[k < angles.size() ? k : angles.size() - 1];
+        k++;
+        RBTransform t = RBTransform::Identity();
+        t.matrix()(0, 0) = std::cos(th);
+        t.matrix()(0, 1) = -std::sin(th);
+        t.matrix()(1, 0) = std::sin(th);
+        t.matrix()(1, 1) = std::cos(th);
+        transform = t;
+        for (auto& m : matches) m.cost = 1.0 + static_cast<double>(k);  // (costs keep changing: only the transform can stop it)
+    }
+};
+
+void test_host_loop_transform_tolerance_3d() {
+    icp::PointCloud3 a(3, 2), b(3, 2);
+    for (int i = 0; i < 2; i++) {
+        a.col(i) << 1.0 * i, 0, 0;
+        b.col(i) << 1.0 * i, 0, 0;
+    }
+    // steps of 3.0 (trace <= 0: the other quaternion branch), 0.1, 0.002, 0.0005: stops at the first step below 1e-3
+    auto spin = std::make_unique<SpinAboutZ>();
+    spin->angles = {3.0, 3.1, 3.102, 3.1025, 3.1026};
+    icp::ICPDriver<icp::Dimension::ThreeD> driver(std::move(spin));
+    driver.set_max_iterations(20);
+    driver.set_transform_tolerance(1e-3, 1e-3);
+    auto r = driver.converge(a, b, icp::RBTransform3::Identity());
+    assert_true(r.iteration_count == 4);
+    // a step of exactly pi about z (trace = -1) is not "no rotation"
+    auto half = std::make_unique<SpinAboutZ>();
+    half->angles = {3.141592653589793, 0.0, 0.0};
+    icp::ICPDriver<icp::Dimension::ThreeD> driver2(std::move(half));
+    driver2.set_max_iterations(20);
+    driver2.set_transform_tolerance(1e-3, 1e-3);
+    auto r2 = driver2.converge(a, b, icp::RBTransform3::Identity());
+    assert_true(r2.iteration_count == 3);  // pi (no stop), back to 0 (a turn of pi again), 0 -> 0 stops
+}
+
 void test_interface_semantics() {
     // registry (icp.h:95-114)
     assert_true(icp::ICP2::is_method_registered("vanilla"));
@@ -336,6 +388,7 @@ int main() {
     test_icp_generic("feature_aware", feature_config);
     test_icp_3d(icp::Config());
     test_interface_semantics();
+    test_host_loop_transform_tolerance_3d();
     std::printf("%d checks, %d failed\n", g_checked, g_failed);
     return g_failed ? 1 : 0;
 }

@@ -187,6 +187,28 @@ dist.destroy_process_group()
     assert "OK" in out.stdout
 
 
+def test_cmake_package_exports_reference_target(tmp_path):
+    """find_package(CevIcp) + CEV::CevIcp, the names the reference exports (CMakeLists.txt:94-100,198-218), resolve to
+    libicpx.so and include/; a consumer compiles and links against them (running it needs no GPU: registry only)."""
+    import shutil
+    if shutil.which("cmake") is None or shutil.which("make") is None:
+        pytest.skip("cmake / make not on PATH")
+    (tmp_path / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.16)\nproject(consumer CXX)\nfind_package(CevIcp 1.3 REQUIRED)\n"
+        "add_executable(app main.cpp)\ntarget_link_libraries(app PRIVATE CEV::CevIcp)\n")
+    (tmp_path / "main.cpp").write_text(
+        '#include <cstdio>\n#include "icp/icp.h"\n#include "icp/driver.h"\n'
+        'int main() { std::printf("%d %d\\n", (int)icp::ICP2::is_method_registered("trimmed"), '
+        '(int)icp::ICP3::registered_methods().size()); return 0; }\n')
+    cfg = subprocess.run(["cmake", "-S", str(tmp_path), "-B", str(tmp_path / "b"), "-G", "Unix Makefiles",
+                          f"-DCevIcp_DIR={ROOT}/cmake"], capture_output=True, text=True, timeout=120)
+    assert cfg.returncode == 0, cfg.stdout[-1500:] + cfg.stderr[-1500:]
+    bld = subprocess.run(["cmake", "--build", str(tmp_path / "b")], capture_output=True, text=True, timeout=240)
+    assert bld.returncode == 0, bld.stdout[-1500:] + bld.stderr[-1500:]
+    run = subprocess.run([str(tmp_path / "b" / "app")], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0 and run.stdout.split() == ["1", "2"], run.stdout + run.stderr
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (before
     anything touches a GPU); --dry-ranks runs the rank plumbing on the CPU over gloo (shard ranges, result gather)
