@@ -48,7 +48,7 @@ SYMBOLS = [
     "icpx_init", "icpx_version", "icpx_last_error", "icpx_default_params", "icpx_create",
     "icpx_destroy", "icpx_begin", "icpx_iterate", "icpx_cost", "icpx_transform", "icpx_matches",
     "icpx_sizes", "icpx_debug_neighbors", "icpx_converge", "icpx_converge_batch", "icpx_nn",
-    "icpx_nn_grid_profile", "icpx_converge_batch_multi", "icpx_debug_knob",
+    "icpx_nn_grid_profile", "icpx_converge_batch_multi", "icpx_debug_knob", "icpx_debug_kd_tree",
     "icpx_converge_batch_noalloc", "icpx_nn_kdtree",
 ]
 
@@ -102,6 +102,7 @@ def _bind(path):
     L.icpx_converge_batch_multi.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.c_int, _vp, C.c_int64, _vp, _vp,
                                             _vp, _vp, _vp, C.POINTER(Criteria), _vp]
     L.icpx_debug_knob.argtypes = [C.c_char_p, C.c_char_p]
+    L.icpx_debug_kd_tree.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
     if hasattr(L, "icpx_converge_batch_noalloc"):
         L.icpx_converge_batch_noalloc.argtypes = L.icpx_converge_batch.argtypes
     L.icpx_nn.argtypes = [C.c_int, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int, C.c_int, _vp]

@@ -331,6 +331,15 @@ def nearest_neighbors(queries, targets, mode=L.NN_AUTO, device=-1, stream=None, 
     return idx, d2
 
 
+def debug_kd_tree(targets, device=-1):
+    """icpx_debug_kd_tree (test hook): the in-order node array of the kd rule's tree, as the device builds it."""
+    lib = L.load()
+    targets = np.ascontiguousarray(targets, np.float64)
+    node = np.zeros(len(targets), np.uint32)
+    L.check(lib.icpx_debug_kd_tree(targets.shape[1], targets.ctypes.data, len(targets), node.ctypes.data, device))
+    return node
+
+
 def nearest_neighbors_kdtree(queries, targets, mode=L.NN_AUTO, device=-1, stream=None):
     """icpx_nn_kdtree: KdTree::search (kdtree.h:79-89) for every query — the target the reference's tree walk
     returns and its Euclidean distance."""

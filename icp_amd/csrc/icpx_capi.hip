@@ -1380,6 +1380,25 @@ int icpx_debug_knob(const char* name, const char* value) {
     });
 }
 
+int icpx_debug_kd_tree(int dim, const double* targets, int64_t m, uint32_t* node_out, int device) {
+    return guarded([&]() -> int {
+    if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
+    if (m <= 0 || !targets || !node_out) return fail(ICPX_ERR_INVALID, "icpx_debug_kd_tree: empty cloud or null pointer");
+    int dev = 0;
+    ICPX_TRY(resolve_device(device, &dev));
+    DeviceGuard g;
+    ICPX_TRY(g.enter(dev));
+    DevBuf t;
+    ICPX_TRY(t.reserve(sizeof(double) * dim * m));
+    int rc = ICPX_OK;
+    hipError_t e = hipMemcpy(t.p, targets, sizeof(double) * dim * m, hipMemcpyDefault);
+    if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "icpx_debug_kd_tree: %s", hipGetErrorString(e));
+    if (rc == ICPX_OK) rc = kd_debug_tree(dim, t.as<double>(), m, node_out, nullptr);
+    t.release();
+    return rc;
+    });
+}
+
 // icpx_nn (kd = false) and icpx_nn_kdtree (kd = true: the kd-tree's tie rule, `d2` receives Euclidean distances)
 static int nn_impl(int dim, const double* queries, int64_t n, const double* targets, int64_t m,
                    int64_t* idx, double* d2, int mode, int device, void* stream_, const bool kd) {

@@ -59,46 +59,37 @@ ICPX_DEV void kd_segment(const int p, const int m, const int levels, int& lo, in
     }
 }
 
-// The tree of one cloud (m >= 1 points, m < 65536; AoS in global memory), built by the calling workgroup.
-//   1. per axis: the cloud's order by (coordinate, index) — bitonic sort of (kd_ord_key, index);
-//   2. level by level (axis = level % D): in the split axis' order every segment [lo, hi) is sorted, its median sits
-//      at mid = lo + (hi - lo - 1) / 2, the points before it form the left child's segment [lo, mid), the points after
-//      it the right child's; the other axes' orders are partitioned the same way, stably (a prefix count over the
-//      whole array, taken relative to the segment's start), so that every segment stays sorted in every axis.
-//      Segments are ranges of in-order positions and depend on m only (kd_segment).
-// After floor(log2 m) + 1 levels every segment is a single point and all orders equal the in-order layout.
-// scratch: kd_build_bytes(D, m) of LDS, 16-byte aligned.  Workgroup-wide (barriers); ends with a barrier behind the
-// global stores (node, pos).
-template <int D, typename I>
-ICPX_DEV void kd_build_lds(const double* __restrict__ pts, const int m, char* scratch, I* __restrict__ node,
-                           I* __restrict__ pos) {
+// Levels the passes run for m points: until every segment holds <= 3 points.  A segment of <= 3 points sorted along
+// its level's axis IS its subtree in order (3: left, node, right; 2: node, right), so the last two levels need no pass.
+ICPX_DEV int kd_pass_levels(const int m) {
+    int k = 0;
+    while ((m >> k) > 3) k++;
+    return k;
+}
+
+// The level passes of the build: ord = the D coordinate orders of the m points ([D][m], u16 ids, each sorted by
+// (coordinate, id)); level k splits along axis (axis0 + k) % D.  u: 8 m + 256 bytes of LDS.  Returns the axis whose
+// order is the in-order layout of the subtree afterwards.  Workgroup-wide; ends with a barrier.
+// seg (optional, [2][m] u16 of LDS): every position's segment bounds carried from level to level; without it they are
+// recomputed by descent from the root (k steps per position and pass: the fused pair kernels, where LDS is scarce).
+template <int D>
+ICPX_DEV int kd_level_passes(uint16_t* ord, const int m, char* u, const int axis0, uint16_t* seg = nullptr) {
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int npad = 2;
-    while (npad < m) npad <<= 1;
-    uint16_t* ord = reinterpret_cast<uint16_t*>(scratch);  // [D][m]
-    char* u = scratch + ((2 * static_cast<size_t>(D) * static_cast<size_t>(m) + 15) & ~static_cast<size_t>(15));
-    uint64_t* skey = reinterpret_cast<uint64_t*>(u);
-    uint32_t* sval = reinterpret_cast<uint32_t*>(skey + npad);
-    for (int a = 0; a < D; a++) {
-        for (int i = tid; i < npad; i += T) {
-            skey[i] = i < m ? kd_ord_key(pts[static_cast<int64_t>(i) * D + a]) : ~0ull;
-            sval[i] = i < m ? static_cast<uint32_t>(i) : 0xffffffffu;
-        }
-        __syncthreads();
-        kd_bitonic_sort(skey, sval, npad, T);
-        for (int p = tid; p < m; p += T) ord[a * m + p] = static_cast<uint16_t>(sval[p]);
-        __syncthreads();
-    }
-    // level passes (the sort arrays are free now)
     uint32_t* E = reinterpret_cast<uint32_t*>(u);          // [m] exclusive prefix of (left | median << 16) flags
     uint16_t* posA = reinterpret_cast<uint16_t*>(E + m);   // [m] position of a point in the split axis' order
     uint16_t* tmp = posA + m;                              // [m]
     int* wtot = reinterpret_cast<int*>(u + 8 * static_cast<size_t>(m));  // [waves]
-    int levels = 1;
-    while ((1 << levels) <= m) levels++;
+    const int levels = kd_pass_levels(m);
     const int C = (m + T - 1) / T;
     const int p0 = min(tid * C, m), p1 = min(p0 + C, m);
-    for (int k = 0, a = 0; k < levels; k++, a = a + 1 == D ? 0 : a + 1) {
+    if (seg) {
+        for (int p = p0; p < p1; p++) {
+            seg[p] = 0;
+            seg[m + p] = static_cast<uint16_t>(m);  // (m <= 65535)
+        }
+    }
+    int a = axis0 % D;
+    for (int k = 0; k < levels; k++, a = a + 1 == D ? 0 : a + 1) {
         for (int p = tid; p < m; p += T) posA[ord[a * m + p]] = static_cast<uint16_t>(p);
         __syncthreads();
         for (int b = 0; b < D; b++) {
@@ -106,7 +97,12 @@ ICPX_DEV void kd_build_lds(const double* __restrict__ pts, const int m, char* sc
             int local = 0;
             for (int p = p0; p < p1; p++) {
                 int lo, hi;
-                kd_segment(p, m, k, lo, hi);
+                if (seg) {
+                    lo = seg[p];
+                    hi = seg[m + p];
+                } else {
+                    kd_segment(p, m, k, lo, hi);
+                }
                 const int mid = lo + ((hi - lo - 1) >> 1);
                 const int pa = posA[ord[b * m + p]];
                 E[p] = static_cast<uint32_t>(local);
@@ -126,7 +122,12 @@ ICPX_DEV void kd_build_lds(const double* __restrict__ pts, const int m, char* sc
             __syncthreads();
             for (int p = p0; p < p1; p++) {
                 int lo, hi;
-                kd_segment(p, m, k, lo, hi);
+                if (seg) {
+                    lo = seg[p];
+                    hi = seg[m + p];
+                } else {
+                    kd_segment(p, m, k, lo, hi);
+                }
                 const int mid = lo + ((hi - lo - 1) >> 1);
                 const int t = ord[b * m + p];
                 const int pa = posA[t];
@@ -139,9 +140,58 @@ ICPX_DEV void kd_build_lds(const double* __restrict__ pts, const int m, char* sc
             for (int p = tid; p < m; p += T) ord[b * m + p] = tmp[p];
             __syncthreads();
         }
+        if (seg) {  // one more split of every own position's segment (own entries only: no barrier)
+            for (int p = p0; p < p1; p++) {
+                const int lo = seg[p], hi = seg[m + p];
+                const int mid = lo + ((hi - lo - 1) >> 1);
+                if (p == mid) {
+                    seg[p] = static_cast<uint16_t>(mid);
+                    seg[m + p] = static_cast<uint16_t>(mid + 1);
+                } else if (p < mid) {
+                    seg[m + p] = static_cast<uint16_t>(mid);
+                } else {
+                    seg[p] = static_cast<uint16_t>(mid + 1);
+                }
+            }
+        }
     }
+    return a;
+}
+
+// The tree of one cloud (m >= 1 points, m < 65536; AoS in global memory), built by the calling workgroup.
+//   1. per axis: the cloud's order by (coordinate, index) — bitonic sort of (kd_ord_key, index);
+//   2. level by level (axis = level % D): in the split axis' order every segment [lo, hi) is sorted, its median sits
+//      at mid = lo + (hi - lo - 1) / 2, the points before it form the left child's segment [lo, mid), the points after
+//      it the right child's; the other axes' orders are partitioned the same way, stably (a prefix count over the
+//      whole array, taken relative to the segment's start), so that every segment stays sorted in every axis.
+//      Segments are ranges of in-order positions and depend on m only (kd_segment).
+// The passes stop when every segment holds <= 3 points (kd_pass_levels): the order along that level's axis then is the
+// in-order layout.
+// scratch: kd_build_bytes(D, m) of LDS, 16-byte aligned.  Workgroup-wide (barriers); ends with a barrier behind the
+// global stores (node, pos).
+template <int D, typename I>
+ICPX_DEV void kd_build_lds(const double* __restrict__ pts, const int m, char* scratch, I* __restrict__ node,
+                           I* __restrict__ pos, uint16_t* seg = nullptr) {
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int npad = 2;
+    while (npad < m) npad <<= 1;
+    uint16_t* ord = reinterpret_cast<uint16_t*>(scratch);  // [D][m]
+    char* u = scratch + ((2 * static_cast<size_t>(D) * static_cast<size_t>(m) + 15) & ~static_cast<size_t>(15));
+    uint64_t* skey = reinterpret_cast<uint64_t*>(u);
+    uint32_t* sval = reinterpret_cast<uint32_t*>(skey + npad);
+    for (int a = 0; a < D; a++) {
+        for (int i = tid; i < npad; i += T) {
+            skey[i] = i < m ? kd_ord_key(pts[static_cast<int64_t>(i) * D + a]) : ~0ull;
+            sval[i] = i < m ? static_cast<uint32_t>(i) : 0xffffffffu;
+        }
+        __syncthreads();
+        kd_bitonic_sort(skey, sval, npad, T);
+        for (int p = tid; p < m; p += T) ord[a * m + p] = static_cast<uint16_t>(sval[p]);
+        __syncthreads();
+    }
+    const int fa = kd_level_passes<D>(ord, m, u, 0, seg);  // (the sort arrays are free now)
     for (int p = tid; p < m; p += T) {
-        const int t = ord[p];
+        const int t = ord[fa * m + p];
         node[p] = static_cast<I>(t);
         pos[t] = static_cast<I>(p);
     }

@@ -34,7 +34,7 @@ struct KdTies {
 };
 // The reference's median-split tree (kdtree.h:96-116; equal coordinates ordered by index) of m host-resident points,
 // in in-order layout: node[p] = point at in-order position p, pos = its inverse.
-void kd_build_host(int dim, const double* pts, int64_t m, uint32_t* node, uint32_t* pos);
+int kd_debug_tree(int dim, const double* d_t, int64_t m, uint32_t* h_node, hipStream_t stream);
 // After a query with KdTies on `stream`: resolves the flagged queries (tree built on the host when there are any).
 // d_q: the queries, d_idx: their (d2, index) answers, corrected in place.  Synchronises the stream.
 int kd_resolve_queries(int dim, const double* d_q, int64_t n, const double* d_t, int64_t m, const KdTies& ties,

@@ -33,6 +33,7 @@
 #include "icpx_bvh.h"
 #include "icpx_grid.h"
 #include "icpx_kd.h"
+#include "icpx_kd_build.h"
 #include "icpx_large.h"
 #include "icpx_math.h"
 
@@ -153,6 +154,12 @@ struct LargeIcp {
     bool kd_rule = false;    // the method takes its neighbours from KdTree::search (vanilla 2D, both 3D)
     bool kd_ready = false;   // kd_tree holds the tree of this begin()'s target cloud
     DevBuf kd_list, kd_tree; // n query indices; [node m][pos m]
+    DevBuf kd_scratch;       // kd_build_device's working arrays
+    // clouds up to kKdEagerMax points: the tree is built at begin() on a stream of its own, beside the first
+    // correspondence step; the first resolve launch waits for it (larger clouds: on demand, after a stall)
+    hipStream_t kd_stream = nullptr;
+    hipEvent_t kd_ev_cloud = nullptr, kd_ev_tree = nullptr;
+    bool kd_wait = false;    // the main stream has not yet waited for kd_ev_tree
     int* h_done = nullptr;  // pinned: [0] done flag, [1] iterations finished, [2] stalled at a tie (written by the device, large_converge polls)
     int* h_done_dev = nullptr;   // the same memory as the device sees it
     int* poll_dev = nullptr;     // h_done_dev while large_converge runs, else null: kernels then publish nothing
@@ -168,7 +175,7 @@ struct LargeIcp {
 namespace {
 
 template <int D>
-__global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost, int update_cost) {
+__global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost, int update_cost, int kd_ready) {
     constexpr int XN = (D + 1) * (D + 1);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int e = 0; e < 16; e++) {
@@ -192,7 +199,7 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost
     dev->dmax_key = 0;
     dev->fcent[0] = dev->fcent[1] = 0.0;
     dev->kd_count = 0;
-    dev->kd_ready = 0;
+    dev->kd_ready = kd_ready;
     dev->kd_stall = 0;
 }
 
@@ -1533,53 +1540,108 @@ int bvh_nn_oneshot(BvhIndex* b, int dim, const double* d_q, int64_t n, const dou
 // kd-tree tie rule, host side (icpx_kd.h)
 // ------------------------------------------------------------------------------------------
 
-namespace {
-inline uint64_t kd_ord_key_host(double v) {
-    uint64_t b;
-    std::memcpy(&b, &v, sizeof(b));
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-}
-// node[lo, hi): the subtree's points in any order -> in-order layout (kdtree.h:96-116 with std::nth_element, under the
-// total order (coordinate, index): the result does not depend on the standard library)
-void kd_build_range(int dim, const double* pts, uint32_t* node, int64_t lo, int64_t hi, int depth, int spawn) {
-    while (hi - lo > 1) {
-        const int axis = depth % dim;
-        const int64_t mid = lo + (hi - lo - 1) / 2;
-        std::nth_element(node + lo, node + mid, node + hi, [pts, dim, axis](uint32_t x, uint32_t y) {
-            const uint64_t kx = kd_ord_key_host(pts[static_cast<int64_t>(x) * dim + axis]);
-            const uint64_t ky = kd_ord_key_host(pts[static_cast<int64_t>(y) * dim + axis]);
-            return kx < ky || (kx == ky && x < y);
-        });
-        if (spawn > 0 && hi - lo > 32768) {
-            std::thread left(kd_build_range, dim, pts, node, lo, mid, depth + 1, spawn - 1);
-            kd_build_range(dim, pts, node, mid + 1, hi, depth + 1, spawn - 1);
-            left.join();
-            return;
+// The tree of the device-resident cloud d_t (m points) into d_node / d_pos (m entries each), built on the device
+// (icpx_kd_build.h); everything is enqueued on the stream, nothing synchronises.  scratch: grown as needed.
+constexpr int64_t kKdEagerMax = 65536;
+
+int kd_build_device(int dim, const double* d_t, int64_t m, uint32_t* d_node, uint32_t* d_pos, DevBuf* scratch, hipStream_t stream) {
+    if (m <= 0) return ICPX_OK;
+    if (m > 0x7fffffff) return fail(ICPX_ERR_UNSUPPORTED, "kd rule: target cloud above 2^31 points");
+    const int M = static_cast<int>(m);
+    static std::mutex mu;
+    static std::unordered_map<int, bool> attr_set;
+    int devid = 0;
+    ICPX_HIP(hipGetDevice(&devid));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!attr_set[devid]) {
+            for (const void* k : {reinterpret_cast<const void*>(kd_small_kernel<2>), reinterpret_cast<const void*>(kd_small_kernel<3>),
+                                  reinterpret_cast<const void*>(kd_segment_kernel<2>), reinterpret_cast<const void*>(kd_segment_kernel<3>)})
+                ICPX_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[devid] = true;
         }
-        kd_build_range(dim, pts, node, lo, mid, depth + 1, 0);
-        lo = mid + 1;
-        depth++;
     }
-}
-}  // namespace
-
-void kd_build_host(int dim, const double* pts, int64_t m, uint32_t* node, uint32_t* pos) {
-    std::iota(node, node + m, 0u);
-    kd_build_range(dim, pts, node, 0, m, 0, 3);  // up to 8 threads on the top levels of large clouds
-    for (int64_t p = 0; p < m; p++) pos[node[p]] = static_cast<uint32_t>(p);
-}
-
-// tree of the device-resident cloud d_t into the two device arrays (each m entries); synchronises the stream
-int kd_tree_to_device(int dim, const double* d_t, int64_t m, uint32_t* d_node, uint32_t* d_pos, hipStream_t stream) {
-    std::vector<double> pts(static_cast<size_t>(m) * dim);
-    ICPX_HIP(hipMemcpyAsync(pts.data(), d_t, sizeof(double) * pts.size(), hipMemcpyDeviceToHost, stream));
-    ICPX_HIP(hipStreamSynchronize(stream));
-    std::vector<uint32_t> node(static_cast<size_t>(m)), pos(static_cast<size_t>(m));
-    kd_build_host(dim, pts.data(), m, node.data(), pos.data());
-    ICPX_HIP(hipMemcpyAsync(d_node, node.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, stream));
-    ICPX_HIP(hipMemcpyAsync(d_pos, pos.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, stream));
-    ICPX_HIP(hipStreamSynchronize(stream));  // (the host vectors go out of scope)
+    if (M <= kKdOneBlock) {
+        const size_t lds = ((kd_build_bytes(dim, M) + 15) & ~size_t(15)) + 4 * static_cast<size_t>(M);
+        if (dim == 2) hipLaunchKernelGGL(kd_small_kernel<2>, dim3(1), dim3(kKdBuildThreads), lds, stream, d_t, M, d_node, d_pos);
+        else hipLaunchKernelGGL(kd_small_kernel<3>, dim3(1), dim3(kKdBuildThreads), lds, stream, d_t, M, d_node, d_pos);
+        ICPX_HIP(hipGetLastError());
+        return ICPX_OK;
+    }
+    // scratch: keys | keys_out | iota | D orders | tmp | posA | library temp
+    size_t sort_bytes = 0, scan_bytes = 0;
+    ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, static_cast<unsigned long long*>(nullptr),
+                                                static_cast<unsigned long long*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                                static_cast<uint32_t*>(nullptr), M, 0, 64, stream));
+    {
+        KdFlag f{nullptr, nullptr, M, 0};
+        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), f);
+        ICPX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, in, static_cast<unsigned long long*>(nullptr), 0ull, static_cast<size_t>(M),
+                                         rocprim::plus<unsigned long long>(), stream));
+    }
+    const size_t lib_bytes = (std::max(sort_bytes, scan_bytes) + 255) & ~size_t(255);
+    const size_t w8 = (sizeof(uint64_t) * m + 255) & ~size_t(255), w4 = (sizeof(uint32_t) * m + 255) & ~size_t(255);
+    ICPX_TRY(scratch->reserve(2 * w8 + (3 + dim) * w4 + lib_bytes));
+    char* base = static_cast<char*>(scratch->p);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(base);
+    unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(base + w8);
+    uint32_t* iota = reinterpret_cast<uint32_t*>(base + 2 * w8);
+    uint32_t* bufs[4];  // D orders + one spare, rotating
+    for (int b = 0; b <= dim; b++) bufs[b] = reinterpret_cast<uint32_t*>(base + 2 * w8 + (1 + b) * w4);
+    uint32_t* posA = reinterpret_cast<uint32_t*>(base + 2 * w8 + (2 + dim) * w4);
+    void* lib = base + 2 * w8 + (3 + dim) * w4;
+    const unsigned nb = static_cast<unsigned>((M + 255) / 256);
+    uint32_t* ord[3] = {bufs[0], bufs[1], bufs[2]};
+    uint32_t* spare = bufs[dim];
+    for (int a = 0; a < dim; a++) {
+        if (dim == 2) hipLaunchKernelGGL(kd_keys_kernel<2>, dim3(nb), dim3(256), 0, stream, d_t, M, a, keys, iota);
+        else hipLaunchKernelGGL(kd_keys_kernel<3>, dim3(nb), dim3(256), 0, stream, d_t, M, a, keys, iota);
+        ICPX_HIP(hipGetLastError());
+        size_t bytes = lib_bytes;
+        ICPX_HIP(hipcub::DeviceRadixSort::SortPairs(lib, bytes, keys, keys_out, iota, ord[a], M, 0, 64, stream));
+    }
+    int K = 0;
+    while ((M >> K) > kKdSegMax) K++;
+    unsigned long long* E = keys;  // (the sort keys are no longer needed)
+    for (int k = 0; k < K; k++) {
+        const int a = k % dim;
+        hipLaunchKernelGGL(kd_pos_kernel, dim3(nb), dim3(256), 0, stream, ord[a], M, posA);
+        ICPX_HIP(hipGetLastError());
+        for (int b = 0; b < dim; b++) {
+            if (b == a) continue;
+            KdFlag f{ord[b], posA, M, k};
+            auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), f);
+            size_t bytes = lib_bytes;
+            ICPX_HIP(rocprim::exclusive_scan(lib, bytes, in, E, 0ull, static_cast<size_t>(M), rocprim::plus<unsigned long long>(), stream));
+            hipLaunchKernelGGL(kd_scatter_kernel, dim3(nb), dim3(256), 0, stream, ord[b], posA, E, M, k, spare);
+            ICPX_HIP(hipGetLastError());
+            std::swap(ord[b], spare);
+        }
+    }
+    hipLaunchKernelGGL(kd_fill_kernel, dim3(nb), dim3(256), 0, stream, ord[0], M, d_node, d_pos);
+    ICPX_HIP(hipGetLastError());
+    KdOrders ords{{ord[0], ord[1], dim == 3 ? ord[2] : nullptr}};
+    const int seg_cap = std::min(kKdSegMax, (M >> K) + 1);
+    const size_t lds = kd_segment_lds_bytes(dim, seg_cap);
+    if (dim == 2) hipLaunchKernelGGL(kd_segment_kernel<2>, dim3(1u << K), dim3(kKdBuildThreads), lds, stream, ords, M, K, posA, d_node, d_pos);
+    else hipLaunchKernelGGL(kd_segment_kernel<3>, dim3(1u << K), dim3(kKdBuildThreads), lds, stream, ords, M, K, posA, d_node, d_pos);
+    ICPX_HIP(hipGetLastError());
     return ICPX_OK;
+}
+
+// test hook (icpx_debug_kd_tree): the in-order node array of a cloud's tree, as the device builds it
+int kd_debug_tree(int dim, const double* d_t, int64_t m, uint32_t* h_node, hipStream_t stream) {
+    DevBuf tree, scratch;
+    int rc = tree.reserve(sizeof(uint32_t) * 2 * static_cast<size_t>(m));
+    if (rc == ICPX_OK) rc = kd_build_device(dim, d_t, m, tree.as<uint32_t>(), tree.as<uint32_t>() + m, &scratch, stream);
+    if (rc == ICPX_OK) {
+        hipError_t e = hipMemcpyAsync(h_node, tree.p, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "kd_debug_tree: %s", hipGetErrorString(e));
+    }
+    tree.release();
+    scratch.release();
+    return rc;
 }
 
 int kd_launch_resolve(int dim, const int* d_count, const uint32_t* d_list, int mode, const double* src, const double* cur,
@@ -1603,11 +1665,10 @@ int kd_resolve_queries(int dim, const double* d_q, int64_t n, const double* d_t,
     int count = 0;
     ICPX_HIP(hipMemcpyAsync(&count, ties.count, sizeof(int), hipMemcpyDeviceToHost, stream));
     ICPX_HIP(hipStreamSynchronize(stream));
-    if (std::getenv("ICPX_KD_DEBUG")) std::fprintf(stderr, "[icpx kd] stand-alone query: %d flagged of %lld\n", count, (long long)n);
     if (count <= 0 || m <= 0 || d_idx == nullptr) return ICPX_OK;
-    DevBuf tree;
+    DevBuf tree, scratch;
     int rc = tree.reserve(sizeof(uint32_t) * 2 * static_cast<size_t>(m));
-    if (rc == ICPX_OK) rc = kd_tree_to_device(dim, d_t, m, tree.as<uint32_t>(), tree.as<uint32_t>() + m, stream);
+    if (rc == ICPX_OK) rc = kd_build_device(dim, d_t, m, tree.as<uint32_t>(), tree.as<uint32_t>() + m, &scratch, stream);
     if (rc == ICPX_OK)
         rc = kd_launch_resolve(dim, ties.count, ties.list, 1, d_q, nullptr, nullptr, tree.as<uint32_t>(), tree.as<uint32_t>() + m, d_t, m,
                                d_idx, count < 4096 ? count : 4096, stream);
@@ -1616,6 +1677,7 @@ int kd_resolve_queries(int dim, const double* d_q, int64_t n, const double* d_t,
         if (e != hipSuccess) rc = fail(ICPX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     }
     tree.release();
+    scratch.release();
     return rc;
 }
 
@@ -1654,9 +1716,15 @@ int large_create(int dim, int method, const icpx_params& prm, double clock_to_s,
 void large_destroy(LargeIcp* lg) {
     if (!lg) return;
     (void)hipStreamSynchronize(lg->stream);
+    if (lg->kd_stream) {
+        (void)hipStreamSynchronize(lg->kd_stream);
+        (void)hipStreamDestroy(lg->kd_stream);
+    }
+    if (lg->kd_ev_cloud) (void)hipEventDestroy(lg->kd_ev_cloud);
+    if (lg->kd_ev_tree) (void)hipEventDestroy(lg->kd_ev_tree);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
                       &lg->cntp, &lg->dev, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
-                      &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree})
+                      &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree, &lg->kd_scratch})
         b->release();
     grid_destroy(lg->grid);
     bvh_destroy(lg->bvh);
@@ -1759,6 +1827,10 @@ template <int D, int MODE>
 int enqueue_kd_resolve(LargeIcp* lg) {
     if (!lg->kd_rule || !lg->kd_ready || MODE == 2) return ICPX_OK;
     LargeDev* dev = lg->dev.as<LargeDev>();
+    if (lg->kd_wait) {
+        ICPX_HIP(hipStreamWaitEvent(lg->stream, lg->kd_ev_tree, 0));
+        lg->kd_wait = false;
+    }
     return kd_launch_resolve(D, &dev->kd_count, lg->kd_list.as<uint32_t>(), MODE, lg->src.as<double>(), lg->cur.as<double>(),
                              dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
                              lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream);
@@ -1860,7 +1932,7 @@ int enqueue_setup(LargeIcp* lg, int check, const icpx_criteria& crit, double hos
     const int update_cost = ((D == 2 && METHOD != ICPX_VANILLA) || match_tf || fill3) ? 1 : 0;
     lg->init_at = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(lg_init_kernel<D>, dim3(1), dim3(64), 0, lg->stream, dev, lg->guess.as<double>(), with_cost,
-                       update_cost);
+                       update_cost, lg->kd_ready ? 1 : 0);
     ICPX_HIP(hipGetLastError());
     if (D == 2) {
         if (lg->feature) ICPX_TRY(enqueue_feature_setup(lg));
@@ -1938,23 +2010,10 @@ int lg_kd_service(LargeIcp* lg, int mode, bool* stalled) {
     int stall = 0;
     ICPX_HIP(hipMemcpyAsync(&stall, &dev->kd_stall, sizeof(int), hipMemcpyDeviceToHost, lg->stream));
     ICPX_HIP(hipStreamSynchronize(lg->stream));
-    if (std::getenv("ICPX_KD_DEBUG")) {
-        int cnt = -1, rdy = -1;
-        (void)hipMemcpy(&cnt, &dev->kd_count, sizeof(int), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&rdy, &dev->kd_ready, sizeof(int), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "[icpx kd] service: stall %d count %d ready %d mode %d bvh %d tile %d\n", stall, cnt, rdy, mode, (int)lg->use_bvh, (int)lg->tile);
-        if (cnt > 0 && cnt < 200) {
-            std::vector<uint32_t> l(cnt);
-            (void)hipMemcpy(l.data(), lg->kd_list.p, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost);
-            std::sort(l.begin(), l.end());
-            std::fprintf(stderr, "[icpx kd] list:");
-            for (uint32_t v : l) std::fprintf(stderr, " %u", v);
-            std::fprintf(stderr, "\n");
-        }
-    }
     if (!stall) return ICPX_OK;
     ICPX_TRY(lg->kd_tree.reserve(sizeof(uint32_t) * 2 * static_cast<size_t>(lg->m)));
-    ICPX_TRY(kd_tree_to_device(lg->dim, lg->dst.as<double>(), lg->m, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m, lg->stream));
+    ICPX_TRY(kd_build_device(lg->dim, lg->dst.as<double>(), lg->m, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
+                             &lg->kd_scratch, lg->stream));
     lg->kd_ready = true;
     hipLaunchKernelGGL(lg_kd_resume_kernel, dim3(1), dim3(64), 0, lg->stream, dev);
     ICPX_HIP(hipGetLastError());
@@ -2006,7 +2065,23 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     lg->feature = D == 2 && lg->method == ICPX_FEATURE_AWARE;
     lg->kd_rule = !lg->feature && (D == 3 || lg->method == ICPX_VANILLA);
     lg->kd_ready = false;
+    lg->kd_wait = false;
     if (lg->kd_rule) ICPX_TRY(lg->kd_list.reserve(sizeof(uint32_t) * n));
+    if (lg->kd_rule && m <= kKdEagerMax) {
+        if (!lg->kd_stream) {
+            ICPX_HIP(hipStreamCreateWithFlags(&lg->kd_stream, hipStreamNonBlocking));
+            ICPX_HIP(hipEventCreateWithFlags(&lg->kd_ev_cloud, hipEventDisableTiming));
+            ICPX_HIP(hipEventCreateWithFlags(&lg->kd_ev_tree, hipEventDisableTiming));
+        }
+        ICPX_TRY(lg->kd_tree.reserve(sizeof(uint32_t) * 2 * static_cast<size_t>(m)));
+        ICPX_HIP(hipEventRecord(lg->kd_ev_cloud, lg->stream));  // (the target cloud is on the device; earlier converges are over)
+        ICPX_HIP(hipStreamWaitEvent(lg->kd_stream, lg->kd_ev_cloud, 0));
+        ICPX_TRY(kd_build_device(D, lg->dst.as<double>(), m, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + m, &lg->kd_scratch,
+                                 lg->kd_stream));
+        ICPX_HIP(hipEventRecord(lg->kd_ev_tree, lg->kd_stream));
+        lg->kd_ready = true;
+        lg->kd_wait = true;
+    }
     if (D == 2 && lg->method != ICPX_VANILLA) {
         // trimmed.cpp:57-58, feature_aware.cpp:92-93 (overlap_rate > 1 would read out of range there; clamped here)
         long long k = static_cast<long long>(lg->prm.overlap_rate * static_cast<double>(n));

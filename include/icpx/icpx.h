@@ -251,6 +251,12 @@ int icpx_converge_batch_noalloc(int dim, int method, const icpx_params* params, 
  * results; they select between kernels.  Not thread-safe against running calls. */
 int icpx_debug_knob(const char* name, const char* value);
 
+/* Test hook (no reference counterpart as a call; the structure is KdTree::build_tree, kdtree.h:96-116): the
+ * median-split tree the kd-tree tie rule uses, as the DEVICE builds it, in in-order layout — node_out[p] = the
+ * target at in-order position p (m entries, host memory); equal split coordinates are ordered by index.
+ * targets: host or device memory. */
+int icpx_debug_kd_tree(int dim, const double* targets, int64_t m, uint32_t* node_out, int device);
+
 /* Measurement helper (no counterpart in the reference): one build + one query of the uniform-grid
  * search with device-memory inputs (queries, targets must be device pointers), timed with HIP
  * events on `stream`.  out[0] = build ms, out[1] = query ms, out[2] = mean number of target records

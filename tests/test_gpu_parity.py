@@ -7,11 +7,12 @@ Bars (tier ③): correspondence indices and squared distances BIT-EXACT against 
 against the oracle in the reference's summation order.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
-from conftest import (BENCH_CRIT, PLY_CRIT, TEST_CRIT, check_case_2d, check_case_3d,
+from conftest import (BENCH_CRIT, GOLDEN, PLY_CRIT, TEST_CRIT, check_case_2d, check_case_3d,
                       reference_cases_2d, reference_cases_3d, tie_clouds)
 
 pytestmark = pytest.mark.gpu
@@ -183,6 +184,27 @@ def test_kd_tie_rule_in_converge(icp, ob, path, knob):
         r = driver(icp, icp.ICP3, method, crit, cfg).converge(q, t)
         ro = o.converge(q, t, None, ob.make_criteria(**crit))
         assert r.iteration_count == ro.iteration_count and np.array_equal(r.transform, ro.transform), method
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_device_built_kd_tree_equals_oracle_tree(icp, ob, dim):
+    """The median-split tree (kdtree.h:96-116; equal coordinates by index) the device builds for the kd rule — one
+    workgroup in LDS up to 4096 points, device-wide sorts + level passes + one workgroup per subtree beyond — against
+    the oracle's KdCanon, node for node: sizes around every switch of the build, clouds with repeated coordinates
+    (a lattice: every split axis has many equal values) and queen.ply (1 956 duplicate vertices)."""
+    from icp_amd import api
+    rng = np.random.default_rng(77 + dim)
+    one_query = np.zeros((1, dim))
+    clouds = [rng.normal(size=(m, dim)) for m in (1, 2, 3, 7, 100, 4095, 4096, 4097, 8192, 8193, 16385, 70001, 300007)]
+    clouds.append(rng.integers(0, 12, size=(9000, dim)).astype(np.float64))      # heavy repeats on every axis
+    clouds.append(np.round(rng.normal(size=(20000, dim)), 1))
+    if dim == 3:
+        from icp_amd import io as iio
+        clouds.append(iio.read_ply_vertices(os.path.join(GOLDEN, "ex_data", "ply", "queen.ply")))
+    for t in clouds:
+        want = ob.nn_kdcanon(one_query, t, want_nodes=True)[2]
+        got = api.debug_kd_tree(t, device=0)
+        assert np.array_equal(got.astype(np.int64), want.astype(np.int64)), (dim, len(t), np.nonzero(got != want)[0][:8])
 
 
 def test_kd_tie_rule_in_batches(icp, ob):
