@@ -125,13 +125,14 @@ ICPX_DEV void kd_query_of(const int mode, const double* __restrict__ src, const 
 
 constexpr int kKdResolveThreads = 256;
 
-// count: device word (number of flagged queries); nb_idx: in = the (d2, index) minimum's target, out = the rule's.
+// count: device word (number of flagged queries); nb_idx: in = the (d2, index) minimum's target, out = the rule's;
+// nb_pt (may be null): out = that target's coordinates.
 // nb_d2 (may be null): receives nothing new (all tied targets share sqrt(d2)); the minimum's d2 is recomputed here.
 template <int D>
 __global__ void __launch_bounds__(kKdResolveThreads)
 kd_resolve_kernel(const int* __restrict__ count, const uint32_t* __restrict__ list, const int mode,
                   const double* __restrict__ src, const double* __restrict__ cur, const double* __restrict__ xf,
-                  const KdView<uint32_t> kd, int64_t* __restrict__ nb_idx) {
+                  const KdView<uint32_t> kd, int64_t* __restrict__ nb_idx, double* __restrict__ nb_pt) {
     __shared__ unsigned long long s_key[kKdResolveThreads / 64];
     __shared__ int s_idx[kKdResolveThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,7 +207,13 @@ kd_resolve_kernel(const int* __restrict__ count, const uint32_t* __restrict__ li
         if (lane == 0) s_idx[wave] = lowest;
         __syncthreads();
         for (int ww = 0; ww < W; ww++) lowest = min(lowest, s_idx[ww]);
-        if (tid == 0) nb_idx[i] = lowest;
+        if (tid == 0) {
+            nb_idx[i] = lowest;
+            if (nb_pt) {  // (the multi-kernel path keeps the matched target's coordinates beside its index)
+#pragma unroll
+                for (int d = 0; d < D; d++) nb_pt[i * D + d] = kd.pts[static_cast<int64_t>(lowest) * D + d];
+            }
+        }
     }
 }
 

@@ -172,7 +172,7 @@ ICPX_DEV int kd_level_passes(uint16_t* ord, const int m, char* u, const int axis
 template <int D, typename I>
 ICPX_DEV void kd_build_lds(const double* __restrict__ pts, const int m, char* scratch, I* __restrict__ node,
                            I* __restrict__ pos, uint16_t* seg = nullptr) {
-    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = blockDim.x, tid = threadIdx.x;
     int npad = 2;
     while (npad < m) npad <<= 1;
     uint16_t* ord = reinterpret_cast<uint16_t*>(scratch);  // [D][m]

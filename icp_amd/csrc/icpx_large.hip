@@ -46,7 +46,7 @@ constexpr int64_t kLargeMaxN = int64_t(1) << 24;  // <= 4096 block partials -> a
 // up to here (<= 4096 TREE64 groups) the sum kernels write level-1 group sums from many small blocks
 // and the finishing block walks the remaining levels: a few thousand points cannot fill 4096-point blocks
 constexpr int64_t kGroupSumMaxN = int64_t(1) << 18;
-constexpr int kGroupBlk = 256;      // threads per block in that mode: one group per wave
+constexpr int kGroupBlk = 1024;     // threads per block in that mode: one group per wave (a full block: its last one finishes the sum)
 
 struct GridIndex {
     GridParams gp{};
@@ -108,6 +108,7 @@ struct LargeDev {
     int kd_count;     // entries of the list (cleared by the kernel that ends an iteration)
     int kd_ready;     // the target's tree is on the device: kd_resolve_kernel follows every correspondence step
     int kd_stall;     // flagged queries but no tree yet: every kernel returns at once until the host has built it
+    int tick1, tick2; // workgroups of lg_sum1 / lg_sum2 that have written their partials (the last one finishes the sums)
     int _pad2;
 };
 
@@ -137,6 +138,7 @@ struct LargeIcp {
     int tile_qpt = 4;        // queries per thread of the tiled search (large_begin)
     bool nn_seeded = false;  // nb_idx holds the neighbours of an earlier correspondence step of this begin()
     DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
+    DevBuf nb_pt;  // the matched target's coordinates per source point (written with nb_idx): the sums stream them
     // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
     DevBuf sort_keys, sort_iota, sort_order, sort_tmp;
     size_t sort_tmp_bytes = 0;
@@ -201,6 +203,8 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost
     dev->kd_count = 0;
     dev->kd_ready = kd_ready;
     dev->kd_stall = 0;
+    dev->tick1 = 0;
+    dev->tick2 = 0;
 }
 
 // after the host has put the target's tree on the device (lg_kd_service): the stall ends
@@ -227,7 +231,8 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
              int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
              double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh,
-             const double* __restrict__ seed_tgt, const double* __restrict__ cloud, uint32_t* __restrict__ kd_list) {
+             const double* __restrict__ seed_tgt, const double* __restrict__ cloud, uint32_t* __restrict__ kd_list,
+             double* __restrict__ nb_pt) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     // the kd-tree methods follow the reference tree's tie rule (icpx_kd.h): flagged queries go on kd_list
     constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
@@ -262,6 +267,8 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     };
     auto publish = [&](const int64_t i, const double best, const int bi, const int tie) {
         nb_idx[i] = bi;
+#pragma unroll
+        for (int d = 0; d < D; d++) nb_pt[i * D + d] = cloud[static_cast<int64_t>(bi) * D + d];
         if (TIES && tie) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(i);
         if (MODE == 2) {
             nb_cost[i] = best;  // trimmed.cpp:101 squaredNorm; selection comes from lg_select_kernel
@@ -496,8 +503,8 @@ template <int D, int METHOD, int MODE>
 __global__ void __launch_bounds__(256)
 lg_tile_merge_kernel(LargeDev* dev, int respect_done, int64_t n, int splits, const double* __restrict__ part_d2,
                      const int32_t* __restrict__ part_idx, int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost,
-                     uint8_t* __restrict__ sel, double max_distance, const double* __restrict__ cloud = nullptr,
-                     uint32_t* __restrict__ kd_list = nullptr) {
+                     uint8_t* __restrict__ sel, double max_distance, const double* __restrict__ cloud,
+                     uint32_t* __restrict__ kd_list, double* __restrict__ nb_pt) {
     if (lg_skip(dev, respect_done)) return;
     constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -525,6 +532,8 @@ lg_tile_merge_kernel(LargeDev* dev, int respect_done, int64_t n, int splits, con
     if (TIES && tie && best < __builtin_inf()) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(i);
     if (bi == 0x7fffffff) bi = 0;  // nothing finite anywhere (non-finite input): the reference's untouched index
     nb_idx[i] = bi;
+#pragma unroll
+    for (int e = 0; e < D; e++) nb_pt[i * D + e] = cloud[static_cast<int64_t>(bi) * D + e];
     if (MODE == 2) {
         nb_cost[i] = best;
     } else {
@@ -546,6 +555,20 @@ __global__ void lg_select_kernel(const LargeDev* dev, int respect_done, int64_t 
     int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r < n) sel[order[r]] = r < new_n ? 1 : 0;
 }
+
+// Partial sums cross workgroups (and XCDs, each with an L2 of its own) inside one launch: they are written and read
+// with agent-scope accesses, which go to the coherence point instead of asking for the whole L2 to be written back /
+// invalidated by a fence (measured: two __threadfence per workgroup cost 7 us per sum kernel).
+ICPX_DEV void st_agent(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ICPX_DEV double ld_agent(const double* p) {
+    return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+        reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+ICPX_DEV void st_agent_int(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+ICPX_DEV int ld_agent_int(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // TREE64 levels 1 and 2 over this block's 4096 points.  f(i, vals) gives point i's NV terms.
 template <int NV, typename F>
@@ -579,14 +602,14 @@ ICPX_DEV void block_tree(F&& f, int64_t n, double* __restrict__ part, int nblk, 
     }
     __syncthreads();
     if (g_total == 1) {
-        if (tid < NV) part[tid * nblk] = gs[tid * 64];
+        if (tid < NV) st_agent(&part[tid * nblk], gs[tid * 64]);
     } else if (wave == 0) {
         int64_t gl = g_total - (base >> 6);  // groups in this block
 #pragma unroll
         for (int v = 0; v < NV; v++) {
             double x = lane < gl ? gs[v * 64 + lane] : 0.0;
             double s = wave_sum(x);
-            if (lane == 0) part[v * nblk + blockIdx.x] = s;
+            if (lane == 0) st_agent(&part[v * nblk + blockIdx.x], s);
         }
     }
 }
@@ -608,7 +631,7 @@ ICPX_DEV void group_tree(F&& f, int64_t n, double* __restrict__ part, int G1) {
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         double s = wave_sum(vals[v]);
-        if (lane == 0) part[static_cast<int64_t>(v) * G1 + g] = s;
+        if (lane == 0) st_agent(&part[static_cast<int64_t>(v) * G1 + g], s);
     }
 }
 
@@ -621,7 +644,7 @@ template <int NV>
 ICPX_DEV void fin_tree_many(const double* __restrict__ part, int nblk, double* lds, double (&out)[NV]) {
     if (nblk == 1) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) out[v] = part[v];
+        for (int v = 0; v < NV; v++) out[v] = ld_agent(&part[v]);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
@@ -629,7 +652,7 @@ ICPX_DEV void fin_tree_many(const double* __restrict__ part, int nblk, double* l
     for (int t = wave; t < NV * G; t += W) {
         const int v = t / G, g = t - v * G;
         const int j = g * 64 + lane;
-        const double x = j < nblk ? part[static_cast<int64_t>(v) * nblk + j] : 0.0;
+        const double x = j < nblk ? ld_agent(&part[static_cast<int64_t>(v) * nblk + j]) : 0.0;
         const double sum = wave_sum(x);
         if (lane == 0) lds[v * 64 + g] = sum;
     }
@@ -647,12 +670,12 @@ ICPX_DEV void fin_tree_many(const double* __restrict__ part, int nblk, double* l
 }
 
 ICPX_DEV double fin_tree(const double* __restrict__ part, int nblk, double* lds) {
-    if (nblk == 1) return part[0];
+    if (nblk == 1) return ld_agent(&part[0]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
     const int G = (nblk + 63) >> 6;
     for (int g = wave; g < G; g += W) {
         int j = g * 64 + lane;
-        double x = j < nblk ? part[j] : 0.0;
+        double x = j < nblk ? ld_agent(&part[j]) : 0.0;
         double s = wave_sum(x);
         if (lane == 0) lds[g] = s;
     }
@@ -842,77 +865,29 @@ fa_match_kernel(const LargeDev* dev, int respect_done, const double* __restrict_
     part_idx[static_cast<int64_t>(blockIdx.y) * n + i] = bi;
 }
 
-template <int D, int METHOD>
-__global__ void __launch_bounds__(kBlk)
-lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
-               const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
-               const double* __restrict__ nb_cost, const uint8_t* __restrict__ sel, double* __restrict__ part,
-               int* __restrict__ cntp, int nblk, int groups, int* hflags) {
-    __shared__ double gs[(2 * D + 1) * 64];
-    __shared__ int wcnt[kBlk / 64];
-    if (lg_skip(dev, respect_done)) return;
-    if (lg_kd_gate(dev, hflags)) return;  // flagged queries of the kd rule and no tree on the device yet: stall
-    Xf<D> X;
-#pragma unroll
-    for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
-    XfRows<D> xr = xf_rows<D>(X);
-    const bool with_cost = dev->with_cost != 0;
-    auto terms = [&](int64_t i, double (&v)[2 * D + 1]) {
-            double p[D], c[D];
-            if (D == 2) {
-#pragma unroll
-                for (int d = 0; d < D; d++) p[d] = src[i * D + d];
-                xf_apply<D>(xr, p, c);  // a_current = transform * a, vanilla.cpp:33
-            } else {
-#pragma unroll
-                for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
-            }
-            bool s = sel[i] != 0;
-            int64_t j = nb_idx[i];
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                v[d] = s ? c[d] : 0.0;
-                v[D + d] = s ? dst[j * D + d] : 0.0;
-            }
-            v[2 * D] = with_cost ? nb_cost[i] : 0.0;
-        };
-    if (groups) {
-        const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if (g >= nblk) return;
-        const int64_t i = static_cast<int64_t>(g) * 64 + (threadIdx.x & 63);
-        int c = wave_sum_int(i < n ? sel[i] : 0);
-        if ((threadIdx.x & 63) == 0) cntp[g] = c;
-        group_tree<2 * D + 1>(terms, n, part, nblk);
-        return;
-    }
-    int cnt = 0;
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
-    for (int k = 0; k < kSlots; k++) {
-        int64_t i = base + k * kBlk + threadIdx.x;
-        if (i < n) cnt += sel[i];
-    }
-    block_tree<2 * D + 1>(terms, n, part, nblk, gs);
-    cnt = wave_sum_int(cnt);
-    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = cnt;
+// The last workgroup of a sum kernel to have written its partials finishes the sum (what used to be a launch of its
+// own): every thread waits for its (agent-scope) partial stores, one atomic ticket per workgroup tells which one is
+// last, and that one reads the other workgroups' partials with agent-scope loads.
+ICPX_DEV bool last_block_done(int* tick, int* s_flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (this thread's agent-scope stores have completed)
     __syncthreads();
     if (threadIdx.x == 0) {
-        int t = 0;
-        for (int w = 0; w < kBlk / 64; w++) t += wcnt[w];
-        cntp[blockIdx.x] = t;
+        const int t = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == static_cast<int>(gridDim.x) - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = last;
     }
+    __syncthreads();
+    return *s_flag != 0;
 }
 
+// centroids, selected count and cost sum from the partials (vanilla.cpp:35-36 / trimmed.cpp:64-65, icp.h:149-155)
 template <int D>
-__global__ void __launch_bounds__(kBlk)
-lg_fin1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, const int* __restrict__ cntp,
-               int nblk) {
-    __shared__ double lds[(2 * D + 1) * 64];
-    __shared__ int wcnt[kBlk / 64];
-    if (lg_skip(dev, respect_done)) return;
+ICPX_DEV void fin1_body(LargeDev* dev, const double* __restrict__ part, const int* __restrict__ cntp, int nblk, double* lds, int* wcnt) {
     double s[2 * D + 1];
     fin_tree_many<2 * D + 1>(part, nblk, lds, s);
     int c = 0;  // <= 2^24 selected points in all
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) c += cntp[b];
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) c += ld_agent_int(&cntp[b]);
     c = wave_sum_int(c);
     if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -931,10 +906,81 @@ lg_fin1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part,
 
 template <int D, int METHOD>
 __global__ void __launch_bounds__(kBlk)
+lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
+               const double* __restrict__ nb_pt, int64_t n, const double* __restrict__ nb_cost,
+               const uint8_t* __restrict__ sel, double* __restrict__ part, int* __restrict__ cntp, int nblk, int groups,
+               int* hflags) {
+    __shared__ double gs[(2 * D + 1) * 64];
+    __shared__ int wcnt[kBlk / 64];
+    __shared__ int s_last;
+    if (lg_skip(dev, respect_done)) return;
+    if (lg_kd_gate(dev, hflags)) return;  // flagged queries of the kd rule and no tree on the device yet: stall
+    Xf<D> X;
+#pragma unroll
+    for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+    XfRows<D> xr = xf_rows<D>(X);
+    const bool with_cost = dev->with_cost != 0;
+    auto terms = [&](int64_t i, double (&v)[2 * D + 1]) {
+            double p[D], c[D];
+            if (D == 2) {
+#pragma unroll
+                for (int d = 0; d < D; d++) p[d] = src[i * D + d];
+                xf_apply<D>(xr, p, c);  // a_current = transform * a, vanilla.cpp:33
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
+            }
+            bool s = sel[i] != 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                v[d] = s ? c[d] : 0.0;
+                v[D + d] = s ? nb_pt[i * D + d] : 0.0;
+            }
+            v[2 * D] = with_cost ? nb_cost[i] : 0.0;
+        };
+    if (groups) {
+        const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (g < nblk) {
+            const int64_t i = static_cast<int64_t>(g) * 64 + (threadIdx.x & 63);
+            int c = wave_sum_int(i < n ? sel[i] : 0);
+            if ((threadIdx.x & 63) == 0) st_agent_int(&cntp[g], c);
+        }
+        group_tree<2 * D + 1>(terms, n, part, nblk);
+    } else {
+        int cnt = 0;
+        const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
+        for (int k = 0; k < kSlots; k++) {
+            int64_t i = base + k * kBlk + threadIdx.x;
+            if (i < n) cnt += sel[i];
+        }
+        block_tree<2 * D + 1>(terms, n, part, nblk, gs);
+        cnt = wave_sum_int(cnt);
+        if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < kBlk / 64; w++) t += wcnt[w];
+            st_agent_int(&cntp[blockIdx.x], t);
+        }
+    }
+    if (!last_block_done(&dev->tick1, &s_last)) return;
+    fin1_body<D>(dev, part, cntp, nblk, gs, wcnt);
+}
+
+// cross-covariance partials; the last workgroup then takes the Kabsch step, updates the transform and evaluates
+// ICPDriver::should_terminate (fin2_body)
+template <int D, int METHOD>
+ICPX_DEV void fin2_body(LargeDev* dev, const double* __restrict__ part, int nblk, double n_points, int check,
+                        const icpx_criteria& crit, double clock_to_s, double host_elapsed_s, int* hflags, double* lds);
+
+template <int D, int METHOD>
+__global__ void __launch_bounds__(kBlk)
 lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
-               const double* __restrict__ dst, int64_t n, const int64_t* __restrict__ nb_idx,
-               const uint8_t* __restrict__ sel, double* __restrict__ part, int nblk, int groups) {
+               const double* __restrict__ nb_pt, int64_t n, const uint8_t* __restrict__ sel, double* __restrict__ part,
+               int nblk, int groups, double n_points, int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s,
+               int* hflags) {
     __shared__ double gs[D * D * 64];
+    __shared__ int s_last;
     if (lg_skip(dev, respect_done)) return;
     Xf<D> X;
 #pragma unroll
@@ -957,9 +1003,8 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
                 for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
             }
             bool s = sel[i] != 0;
-            int64_t j = nb_idx[i];
 #pragma unroll
-            for (int d = 0; d < D; d++) b[d] = dst[j * D + d];
+            for (int d = 0; d < D; d++) b[d] = nb_pt[i * D + d];
 #pragma unroll
             for (int r = 0; r < D; r++)
 #pragma unroll
@@ -969,6 +1014,8 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
         group_tree<D * D>(terms, n, part, nblk);
     else
         block_tree<D * D>(terms, n, part, nblk, gs);
+    if (!last_block_done(&dev->tick2, &s_last)) return;
+    fin2_body<D, METHOD>(dev, part, nblk, n_points, check, crit, clock_to_s, host_elapsed_s, hflags, gs);
 }
 
 // done flag and iteration count into host memory (pinned, coherent) for large_converge, which polls them instead of
@@ -1002,12 +1049,9 @@ __global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx
 }
 
 template <int D, int METHOD>
-__global__ void __launch_bounds__(kBlk)
-lg_fin2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ part, int nblk, double n_points,
-               int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s, int* hflags) {
-    __shared__ double lds[D * D * 64];
+ICPX_DEV void fin2_body(LargeDev* dev, const double* __restrict__ part, int nblk, double n_points, int check,
+                        const icpx_criteria& crit, double clock_to_s, double host_elapsed_s, int* hflags, double* lds) {
     constexpr int XN = (D + 1) * (D + 1);
-    if (lg_skip(dev, respect_done)) return;
     double s[D * D];
     fin_tree_many<D * D>(part, nblk, lds, s);
     if (threadIdx.x == 0) {
@@ -1646,16 +1690,16 @@ int kd_debug_tree(int dim, const double* d_t, int64_t m, uint32_t* h_node, hipSt
 
 int kd_launch_resolve(int dim, const int* d_count, const uint32_t* d_list, int mode, const double* src, const double* cur,
                       const double* xf, const uint32_t* d_node, const uint32_t* d_pos, const double* d_t, int64_t m,
-                      int64_t* d_idx, int blocks, hipStream_t stream) {
+                      int64_t* d_idx, int blocks, hipStream_t stream, double* d_pt = nullptr) {
     KdView<uint32_t> kd;
     kd.node = d_node;
     kd.pos = d_pos;
     kd.pts = d_t;
     kd.m = static_cast<int>(m);
     if (dim == 2)
-        hipLaunchKernelGGL(kd_resolve_kernel<2>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx);
+        hipLaunchKernelGGL(kd_resolve_kernel<2>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt);
     else
-        hipLaunchKernelGGL(kd_resolve_kernel<3>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx);
+        hipLaunchKernelGGL(kd_resolve_kernel<3>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1723,7 +1767,7 @@ void large_destroy(LargeIcp* lg) {
     if (lg->kd_ev_cloud) (void)hipEventDestroy(lg->kd_ev_cloud);
     if (lg->kd_ev_tree) (void)hipEventDestroy(lg->kd_ev_tree);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
-                      &lg->cntp, &lg->dev, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
+                      &lg->cntp, &lg->dev, &lg->nb_pt, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
                       &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree, &lg->kd_scratch})
         b->release();
     grid_destroy(lg->grid);
@@ -1734,24 +1778,31 @@ void large_destroy(LargeIcp* lg) {
 
 namespace {
 
+inline icpx_criteria zero_criteria() {
+    icpx_criteria c;
+    std::memset(&c, 0, sizeof(c));
+    return c;
+}
+
 template <int D, int METHOD>
-int enqueue_sums(LargeIcp* lg, int respect_done, bool second) {
+int enqueue_sums(LargeIcp* lg, int respect_done, bool second, int check = 0, const icpx_criteria* crit = nullptr,
+                 double host_elapsed_s = 0.0) {
     LargeDev* dev = lg->dev.as<LargeDev>();
     const int nblk = lg->nblk, groups = lg->groups ? 1 : 0;
     const dim3 grid(groups ? (nblk + kGroupBlk / 64 - 1) / (kGroupBlk / 64) : nblk), block(groups ? kGroupBlk : kBlk);
     if (!second) {
+        // centroid / count / cost partials; the last workgroup finishes them (fin1_body)
         hipLaunchKernelGGL((lg_sum1_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
-                           lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->n,
-                           lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(),
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->nb_pt.as<double>(), lg->n,
+                           lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(),
                            lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups, lg->poll_dev);
         ICPX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(lg_fin1_kernel<D>, dim3(1), dim3(kBlk), 0, lg->stream, dev, respect_done,
-                           lg->part.as<double>(), lg->cntp.as<int>(), nblk);
-        ICPX_HIP(hipGetLastError());
     } else {
+        // cross-covariance partials; the last workgroup takes the Kabsch step and evaluates the criteria (fin2_body)
         hipLaunchKernelGGL((lg_sum2_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
-                           lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->n,
-                           lg->nb_idx.as<int64_t>(), lg->sel.as<uint8_t>(), lg->part.as<double>(), nblk, groups);
+                           lg->src.as<double>(), lg->cur.as<double>(), lg->nb_pt.as<double>(), lg->n,
+                           lg->sel.as<uint8_t>(), lg->part.as<double>(), nblk, groups, static_cast<double>(lg->n), check,
+                           crit ? *crit : zero_criteria(), lg->clock_to_s, host_elapsed_s, lg->poll_dev);
         ICPX_HIP(hipGetLastError());
     }
     return ICPX_OK;
@@ -1775,7 +1826,8 @@ int enqueue_feature_match(LargeIcp* lg, int respect) {
     ICPX_HIP(hipGetLastError());
     hipLaunchKernelGGL((lg_tile_merge_kernel<2, ICPX_TRIMMED, 2>), dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n,
                        lg->splits, lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->nb_idx.as<int64_t>(),
-                       lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance);
+                       lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, lg->dst.as<double>(), nullptr,
+                       lg->nb_pt.as<double>());
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1833,7 +1885,7 @@ int enqueue_kd_resolve(LargeIcp* lg) {
     }
     return kd_launch_resolve(D, &dev->kd_count, lg->kd_list.as<uint32_t>(), MODE, lg->src.as<double>(), lg->cur.as<double>(),
                              dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
-                             lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream);
+                             lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream, lg->nb_pt.as<double>());
 }
 
 template <int D, int METHOD, int MODE>
@@ -1857,7 +1909,7 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
                                respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, GridParams{}, nullptr, nullptr,
                                lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance,
                                bv->q_perm_n == lg->n ? bv->q_perm.as<uint32_t>() : nullptr, nullptr, bv->view(), nullptr,
-                               lg->dst.as<double>(), lg->kd_list.as<uint32_t>());
+                               lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>());
             ICPX_HIP(hipGetLastError());
             return ICPX_OK;
         }
@@ -1873,7 +1925,7 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, perm,
                            blk ? g->q_start.as<int>() : nullptr, BvhView{},
                            (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr,
-                           lg->dst.as<double>(), lg->kd_list.as<uint32_t>());
+                           lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>());
         ICPX_HIP(hipGetLastError());
         lg->nn_seeded = true;  // nb_idx now holds this step's neighbours
         return ICPX_OK;
@@ -1906,7 +1958,7 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
     hipLaunchKernelGGL((lg_tile_merge_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n,
                        lg->splits, lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->nb_idx.as<int64_t>(),
                        lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, lg->dst.as<double>(),
-                       lg->kd_list.as<uint32_t>());
+                       lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>());
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1977,12 +2029,7 @@ int enqueue_iteration_tail(LargeIcp* lg, int check, const icpx_criteria& crit, d
         ICPX_HIP(hipGetLastError());
     }
     ICPX_TRY((enqueue_sums<D, METHOD>(lg, respect, false)));
-    ICPX_TRY((enqueue_sums<D, METHOD>(lg, respect, true)));
-    hipLaunchKernelGGL((lg_fin2_kernel<D, METHOD>), dim3(1), dim3(kBlk), 0, lg->stream, dev, respect,
-                       lg->part.as<double>(), lg->nblk, static_cast<double>(lg->n), check, crit, lg->clock_to_s,
-                       host_elapsed_s, lg->poll_dev);
-    ICPX_HIP(hipGetLastError());
-    return ICPX_OK;
+    return enqueue_sums<D, METHOD>(lg, respect, true, check, &crit, host_elapsed_s);
 }
 
 #define LG_DISPATCH(fn, lg, ...)                                                             \
@@ -1990,12 +2037,6 @@ int enqueue_iteration_tail(LargeIcp* lg, int check, const icpx_criteria& crit, d
                                                     : fn<2, ICPX_TRIMMED>(lg, __VA_ARGS__))  \
                     : ((lg)->method == ICPX_VANILLA ? fn<3, ICPX_VANILLA>(lg, __VA_ARGS__)   \
                                                     : fn<3, ICPX_TRIMMED>(lg, __VA_ARGS__)))
-
-icpx_criteria zero_criteria() {
-    icpx_criteria c;
-    std::memset(&c, 0, sizeof(c));
-    return c;
-}
 
 }  // namespace
 
@@ -2019,7 +2060,7 @@ int lg_kd_service(LargeIcp* lg, int mode, bool* stalled) {
     ICPX_HIP(hipGetLastError());
     ICPX_TRY(kd_launch_resolve(lg->dim, &dev->kd_count, lg->kd_list.as<uint32_t>(), mode, lg->src.as<double>(), lg->cur.as<double>(),
                                dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
-                               lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream));
+                               lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream, lg->nb_pt.as<double>()));
     *stalled = true;
     return ICPX_OK;
 }
@@ -2044,6 +2085,7 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     ICPX_TRY(lg->cur.reserve(sizeof(double) * D * n));
     ICPX_TRY(lg->guess.reserve(sizeof(double) * 16));
     ICPX_TRY(lg->nb_idx.reserve(sizeof(int64_t) * n));
+    ICPX_TRY(lg->nb_pt.reserve(sizeof(double) * D * n));
     ICPX_TRY(lg->nb_cost.reserve(sizeof(double) * n));
     ICPX_TRY(lg->sel.reserve(n));
     ICPX_TRY(lg->part.reserve(sizeof(double) * 16 * lg->nblk));

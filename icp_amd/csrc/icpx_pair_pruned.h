@@ -402,12 +402,14 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
     }
 
     // ---- publish ----
-    if (pb.seeds) {
+    // (a converged pair of a batch is never visited again: its running cloud and seeds stay where they are)
+    const bool revisit = !(ls->done != 0 && pb.m_point == nullptr);
+    if (pb.seeds && revisit) {
 #pragma unroll
         for (int k = 0; k < QPT; k++)
             if ((vmask >> k) & 1) pb.seeds[s0 + tid + k * T] = pv.d[k];
     }
-    if (D == 3 && pb.cur) {
+    if (D == 3 && pb.cur && revisit) {
 #pragma unroll
         for (int k = 0; k < QPT; k++)
             if ((vmask >> k) & 1)

@@ -21,3 +21,15 @@ for method in ("vanilla", "trimmed"):
     for _ in range(10):
         r = drv3.converge(qt, q)
     print(method, "queen ms", (time.perf_counter() - t0) / 10 * 1e3, "it", r.iteration_count, flush=True)
+for nn in ("grid", "bvh"):
+    cfg = icp_amd.Config()
+    cfg.set("nn", nn)
+    drv3 = icp_amd.ICPDriver(icp_amd.ICP3.from_method("vanilla", cfg, device=0))
+    drv3.set_max_iterations(100)
+    drv3.set_transform_tolerance(1e-4, 1e-4)
+    r0 = drv3.converge(qt, q)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        r = drv3.converge(qt, q)
+    print("vanilla nn=%s queen ms" % nn, (time.perf_counter() - t0) / 10 * 1e3, "it", r.iteration_count,
+          "same as auto:", np.array_equal(r.transform, r0.transform), flush=True)
