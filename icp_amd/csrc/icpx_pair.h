@@ -1233,9 +1233,10 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX, PRUNE)) pai
             if (pick == -2) continue;
             q = pick >> 1;
             setup = pick & 1;
-            // while at least half as many pairs are waiting as there are workgroups, a task carries two iterations
-            // (half the hand-offs and restagings); in the tail it carries one, for balance
-            task_steps = static_cast<uint64_t>(pb.sched_steps) * (2 * s_ready > static_cast<int>(gridDim.x) ? 2 : 1);
+            // a task carries sched_steps iterations (default 16: a pair is set up and converged in one visit, with no
+            // write-back of its running cloud in between); shorter tasks in the tail were tried for balance and lost
+            // (512 3D pairs: 1.52 -> 1.58 ms per step — every hand-off is a write-back, a release and a restaging)
+            task_steps = static_cast<uint64_t>(pb.sched_steps);
         }
 #ifdef ICPX_STATS
         const uint64_t stat_t0 = wall_clock64();
