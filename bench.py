@@ -338,9 +338,10 @@ def profile_counters():
         try:
             with open(path) as f:
                 k = json.load(f)["kernels"]
-            for name, v in k.items():
-                if "pair_kernel<3, 0" in name:
-                    return "profiles/" + os.path.basename(path), v
+            # (the hot 3D kernel, not the kd rule's take-over kernel launched behind it: the one with the traffic)
+            hot = [v for name, v in k.items() if "pair_kernel<3, 0" in name]
+            if hot:
+                return "profiles/" + os.path.basename(path), max(hot, key=lambda v: v.get("hbm_bytes_per_launch_raw") or 0)
         except (OSError, KeyError, ValueError):
             continue
     return None

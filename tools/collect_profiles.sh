@@ -18,4 +18,6 @@ G="tools/c4_grid_probe.py 3"
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_c4_trace -- python3 $G > $out/${tag}_c4_trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_c4_pmc_fetch -- python3 $G > $out/${tag}_c4_pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_c4_pmc_write -- python3 $G > $out/${tag}_c4_pmc_write.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_c4conv_trace -- python3 tools/c4_converge_probe.py > $out/${tag}_c4conv_trace.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_queen_trace -- python3 tools/queen_probe.py > $out/${tag}_queen_trace.log 2>&1
 echo collected

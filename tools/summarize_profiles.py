@@ -16,6 +16,10 @@ if stats:
 stats = glob.glob(os.path.join(go, f"{tag}_c4_trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(pr, f"{tag}_c4_grid_kernel_stats.csv"))
+for d, name in (("c4conv_trace", "c4_converge_kernel_stats.csv"), ("queen_trace", "queen_kernel_stats.csv")):
+    stats = glob.glob(os.path.join(go, f"{tag}_{d}", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(pr, f"{tag}_{name}"))
 per = defaultdict(lambda: defaultdict(list))
 for d in ("pmc_fetch", "pmc_write", "pmc_valu", "pmc_lds", "c4_pmc_fetch", "c4_pmc_write"):
     for f in glob.glob(os.path.join(go, f"{tag}_{d}", "*", "*_counter_collection.csv")):
