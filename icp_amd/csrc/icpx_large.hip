@@ -139,6 +139,14 @@ struct LargeIcp {
     bool nn_seeded = false;  // nb_idx holds the neighbours of an earlier correspondence step of this begin()
     DevBuf src, dst, cur, guess, nb_idx, nb_cost, sel, part, cntp, dev;
     DevBuf nb_pt;  // the matched target's coordinates per source point (written with nb_idx): the sums stream them
+    // Sorted domain (3D grid search over >= kGridSortMinQueries points): the correspondence kernel visits the points in
+    // the cell order of begin() (q_perm).  It keeps its own copy of the running cloud and the previous neighbours IN
+    // THAT ORDER (cur_s, idx_s: streamed) and scatters only the matched target's coordinates to the point's place
+    // (nb_pt); the sums stream the cloud and nb_pt in point order (TREE64 is defined on point indices), apply the step
+    // to `cur` themselves and recompute the selection from the two points.  nb_idx / nb_cost / sel in point order are
+    // written on demand (sd_unpack).
+    bool sd = false, sd_dirty = false;
+    DevBuf cur_s, idx_s;
     // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
     DevBuf sort_keys, sort_iota, sort_order, sort_tmp;
     size_t sort_tmp_bytes = 0;
@@ -214,6 +222,49 @@ __global__ void lg_kd_resume_kernel(LargeDev* dev) {
     dev->kd_stall = 0;
 }
 
+// sorted domain: the running cloud in the query order of the grid search
+__global__ void lg_sd_gather_kernel(const double* __restrict__ cur, const uint32_t* __restrict__ perm, int64_t n,
+                                    double* __restrict__ cur_s) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = perm[k];
+#pragma unroll
+    for (int d = 0; d < 3; d++) cur_s[k * 3 + d] = cur[i * 3 + d];
+}
+
+// the 3D methods' match cost and selection from the two points (what the correspondence stage publishes otherwise):
+// sqrt of kdtree.h:126's Euclidean distance; Trimmed3d keeps a match when it is <= max_distance (trimmed_3d.cpp:42-49)
+template <int METHOD>
+ICPX_DEV bool sd_select(const double* c, const double* b, const double max_distance, double* cost_out = nullptr) {
+    double df = b[0] - c[0];
+    double d2 = df * df;
+    df = b[1] - c[1];
+    d2 = d2 + df * df;
+    df = b[2] - c[2];
+    d2 = d2 + df * df;
+    const double cost = __builtin_sqrt(__builtin_sqrt(d2));
+    if (cost_out) *cost_out = cost;
+    return METHOD == ICPX_TRIMMED ? cost <= max_distance : true;
+}
+
+// sorted domain -> nb_idx / nb_cost / sel in point order (for the getters)
+template <int METHOD>
+__global__ void lg_sd_unpack_kernel(const double* __restrict__ cur_s, const int64_t* __restrict__ idx_s,
+                                    const uint32_t* __restrict__ perm, const double* __restrict__ cloud, int64_t n,
+                                    double max_distance, int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost,
+                                    uint8_t* __restrict__ sel) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = perm[k], j = idx_s[k];
+    const double c[3] = {cur_s[k * 3], cur_s[k * 3 + 1], cur_s[k * 3 + 2]};
+    const double b[3] = {cloud[j * 3], cloud[j * 3 + 1], cloud[j * 3 + 2]};
+    double cost;
+    const bool s = sd_select<METHOD>(c, b, max_distance, &cost);
+    nb_idx[i] = j;
+    nb_cost[i] = cost;
+    sel[i] = s ? 1 : 0;
+}
+
 // NN stage.  MODE 0: the 3D per-iteration stage.  MODE 1: Vanilla::setup's compute_matches on the
 // untransformed source (vanilla.cpp:68-88).  MODE 2: Trimmed::compute_matches on transform*a with
 // the squared distance as cost (trimmed.cpp:95-109).  MODE 3: Vanilla's compute_matches on
@@ -232,7 +283,7 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
              double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh,
              const double* __restrict__ seed_tgt, const double* __restrict__ cloud, uint32_t* __restrict__ kd_list,
-             double* __restrict__ nb_pt) {
+             double* __restrict__ nb_pt, double* __restrict__ cur_s = nullptr, int64_t* __restrict__ idx_s = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     // the kd-tree methods follow the reference tree's tie rule (icpx_kd.h): flagged queries go on kd_list
     constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
@@ -312,6 +363,52 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     }
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (D == 3 && MODE == 0 && cur_s != nullptr) {
+        // sorted domain (LargeIcp::sd): position k of the query order; only nb_pt goes to the point's own place
+        const int64_t k = i;
+        i = perm[k];
+        double q[D], best;
+        int bi, tie = 0;
+        {
+            Xf<D> S;
+#pragma unroll
+            for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
+            XfRows<D> sr = xf_rows<D>(S);
+            double c[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) c[d] = cur_s[k * D + d];
+            xf_apply<D>(sr, c, q);  // c = T * c, vanilla_3d.cpp:91 (lg_sum1 applies the same step to the cloud in point order)
+#pragma unroll
+            for (int d = 0; d < D; d++) cur_s[k * D + d] = q[d];
+        }
+        bool searched = false;
+        if (seed_tgt) {
+            const int64_t sidx = idx_s[k];
+            bool ok = gp.m > 0;
+            double df = seed_tgt[sidx * D] - q[0];
+            double d2s = df * df;
+#pragma unroll
+            for (int d = 1; d < D; d++) {
+                df = seed_tgt[sidx * D + d] - q[d];
+                d2s = d2s + df * df;
+            }
+#pragma unroll
+            for (int d = 0; d < D; d++) ok = ok && finite_d(q[d]);
+            ok = ok && d2s < __builtin_inf();
+            if (ok) {
+                best = d2s;
+                bi = static_cast<int>(sidx);
+                grid_query_seeded<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
+                searched = true;
+            }
+        }
+        if (!searched) grid_query<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
+        idx_s[k] = bi;
+#pragma unroll
+        for (int d = 0; d < D; d++) nb_pt[i * D + d] = cloud[static_cast<int64_t>(bi) * D + d];
+        if (TIES && tie) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(k);
+        return;
+    }
     if (perm) i = perm[i];  // tile order of the initial cloud: neighbouring lanes walk the same cells
     double q[D], best;
     int bi;
@@ -906,10 +1003,10 @@ ICPX_DEV void fin1_body(LargeDev* dev, const double* __restrict__ part, const in
 
 template <int D, int METHOD>
 __global__ void __launch_bounds__(kBlk)
-lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
+lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
                const double* __restrict__ nb_pt, int64_t n, const double* __restrict__ nb_cost,
                const uint8_t* __restrict__ sel, double* __restrict__ part, int* __restrict__ cntp, int nblk, int groups,
-               int* hflags) {
+               int* hflags, int sd, double max_distance) {
     __shared__ double gs[(2 * D + 1) * 64];
     __shared__ int wcnt[kBlk / 64];
     __shared__ int s_last;
@@ -920,8 +1017,18 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
     for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
     XfRows<D> xr = xf_rows<D>(X);
     const bool with_cost = dev->with_cost != 0;
-    auto terms = [&](int64_t i, double (&v)[2 * D + 1]) {
-            double p[D], c[D];
+    // sorted domain (LargeIcp::sd, 3D): the correspondence kernel stepped its own copy of the cloud; the cloud in point
+    // order takes the same step here (c = T * c, vanilla_3d.cpp:91), and the selection comes from the two points
+    XfRows<D> sr;
+    if (D == 3 && sd) {
+        Xf<D> S;
+#pragma unroll
+        for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
+        sr = xf_rows<D>(S);
+    }
+    // the point (as the sums take it) and whether its match is selected
+    auto point_of = [&](int64_t i, double (&c)[D], double (&b)[D]) -> bool {
+            double p[D];
             if (D == 2) {
 #pragma unroll
                 for (int d = 0; d < D; d++) p[d] = src[i * D + d];
@@ -929,32 +1036,43 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
             } else {
 #pragma unroll
                 for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
+                if (sd) {
+#pragma unroll
+                    for (int d = 0; d < D; d++) p[d] = c[d];
+                    xf_apply<D>(sr, p, c);
+#pragma unroll
+                    for (int d = 0; d < D; d++) cur[i * D + d] = c[d];
+                }
             }
-            bool s = sel[i] != 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) b[d] = nb_pt[i * D + d];
+            if constexpr (D == 3) {
+                if (sd) return sd_select<METHOD>(c, b, max_distance);
+            }
+            return sel[i] != 0;
+        };
+    int my_sel = 0;  // selected among the points this thread took
+    auto terms = [&](int64_t i, double (&v)[2 * D + 1]) {
+            double c[D], b[D];
+            const bool s = point_of(i, c, b);
+            my_sel += s ? 1 : 0;
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 v[d] = s ? c[d] : 0.0;
-                v[D + d] = s ? nb_pt[i * D + d] : 0.0;
+                v[D + d] = s ? b[d] : 0.0;
             }
             v[2 * D] = with_cost ? nb_cost[i] : 0.0;
         };
     if (groups) {
         const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        group_tree<2 * D + 1>(terms, n, part, nblk);
         if (g < nblk) {
-            const int64_t i = static_cast<int64_t>(g) * 64 + (threadIdx.x & 63);
-            int c = wave_sum_int(i < n ? sel[i] : 0);
+            const int c = wave_sum_int(my_sel);
             if ((threadIdx.x & 63) == 0) st_agent_int(&cntp[g], c);
         }
-        group_tree<2 * D + 1>(terms, n, part, nblk);
     } else {
-        int cnt = 0;
-        const int64_t base = static_cast<int64_t>(blockIdx.x) * kBlkPts;
-        for (int k = 0; k < kSlots; k++) {
-            int64_t i = base + k * kBlk + threadIdx.x;
-            if (i < n) cnt += sel[i];
-        }
         block_tree<2 * D + 1>(terms, n, part, nblk, gs);
-        cnt = wave_sum_int(cnt);
+        int cnt = wave_sum_int(my_sel);
         if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = cnt;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -978,7 +1096,7 @@ __global__ void __launch_bounds__(kBlk)
 lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                const double* __restrict__ nb_pt, int64_t n, const uint8_t* __restrict__ sel, double* __restrict__ part,
                int nblk, int groups, double n_points, int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s,
-               int* hflags) {
+               int* hflags, int sd, double max_distance) {
     __shared__ double gs[D * D * 64];
     __shared__ int s_last;
     if (lg_skip(dev, respect_done)) return;
@@ -1002,9 +1120,14 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
 #pragma unroll
                 for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
             }
-            bool s = sel[i] != 0;
 #pragma unroll
             for (int d = 0; d < D; d++) b[d] = nb_pt[i * D + d];
+            // (sorted domain: lg_sum1 has stepped the cloud; the selection comes from the two points)
+            bool s = false;
+            if constexpr (D == 3) {
+                if (sd) s = sd_select<METHOD>(c, b, max_distance);
+            }
+            if (!(D == 3 && sd)) s = sel[i] != 0;
 #pragma unroll
             for (int r = 0; r < D; r++)
 #pragma unroll
@@ -1690,16 +1813,16 @@ int kd_debug_tree(int dim, const double* d_t, int64_t m, uint32_t* h_node, hipSt
 
 int kd_launch_resolve(int dim, const int* d_count, const uint32_t* d_list, int mode, const double* src, const double* cur,
                       const double* xf, const uint32_t* d_node, const uint32_t* d_pos, const double* d_t, int64_t m,
-                      int64_t* d_idx, int blocks, hipStream_t stream, double* d_pt = nullptr) {
+                      int64_t* d_idx, int blocks, hipStream_t stream, double* d_pt = nullptr, const uint32_t* d_perm = nullptr) {
     KdView<uint32_t> kd;
     kd.node = d_node;
     kd.pos = d_pos;
     kd.pts = d_t;
     kd.m = static_cast<int>(m);
     if (dim == 2)
-        hipLaunchKernelGGL(kd_resolve_kernel<2>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt);
+        hipLaunchKernelGGL(kd_resolve_kernel<2>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt, d_perm);
     else
-        hipLaunchKernelGGL(kd_resolve_kernel<3>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt);
+        hipLaunchKernelGGL(kd_resolve_kernel<3>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt, d_perm);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1767,7 +1890,7 @@ void large_destroy(LargeIcp* lg) {
     if (lg->kd_ev_cloud) (void)hipEventDestroy(lg->kd_ev_cloud);
     if (lg->kd_ev_tree) (void)hipEventDestroy(lg->kd_ev_tree);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
-                      &lg->cntp, &lg->dev, &lg->nb_pt, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
+                      &lg->cntp, &lg->dev, &lg->nb_pt, &lg->cur_s, &lg->idx_s, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
                       &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree, &lg->kd_scratch})
         b->release();
     grid_destroy(lg->grid);
@@ -1795,14 +1918,16 @@ int enqueue_sums(LargeIcp* lg, int respect_done, bool second, int check = 0, con
         hipLaunchKernelGGL((lg_sum1_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->nb_pt.as<double>(), lg->n,
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(),
-                           lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups, lg->poll_dev);
+                           lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups, lg->poll_dev, lg->sd ? 1 : 0,
+                           lg->prm.max_distance);
         ICPX_HIP(hipGetLastError());
     } else {
         // cross-covariance partials; the last workgroup takes the Kabsch step and evaluates the criteria (fin2_body)
         hipLaunchKernelGGL((lg_sum2_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->nb_pt.as<double>(), lg->n,
                            lg->sel.as<uint8_t>(), lg->part.as<double>(), nblk, groups, static_cast<double>(lg->n), check,
-                           crit ? *crit : zero_criteria(), lg->clock_to_s, host_elapsed_s, lg->poll_dev);
+                           crit ? *crit : zero_criteria(), lg->clock_to_s, host_elapsed_s, lg->poll_dev, lg->sd ? 1 : 0,
+                           lg->prm.max_distance);
         ICPX_HIP(hipGetLastError());
     }
     return ICPX_OK;
@@ -1883,9 +2008,13 @@ int enqueue_kd_resolve(LargeIcp* lg) {
         ICPX_HIP(hipStreamWaitEvent(lg->stream, lg->kd_ev_tree, 0));
         lg->kd_wait = false;
     }
-    return kd_launch_resolve(D, &dev->kd_count, lg->kd_list.as<uint32_t>(), MODE, lg->src.as<double>(), lg->cur.as<double>(),
+    // (sorted domain: the list holds positions of the query order; queries and neighbours live in cur_s / idx_s)
+    const bool sd = lg->sd && MODE == 0;
+    return kd_launch_resolve(D, &dev->kd_count, lg->kd_list.as<uint32_t>(), MODE, lg->src.as<double>(),
+                             sd ? lg->cur_s.as<double>() : lg->cur.as<double>(),
                              dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
-                             lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream, lg->nb_pt.as<double>());
+                             lg->dst.as<double>(), lg->m, sd ? lg->idx_s.as<int64_t>() : lg->nb_idx.as<int64_t>(), 1024, lg->stream,
+                             lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr);
 }
 
 template <int D, int METHOD, int MODE>
@@ -1918,6 +2047,7 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
         // block-cooperative only on request (ICPX_GRID_COOP=2): the order is that of begin(), and once the running cloud has
         // moved by more than a cell most queries have left their block's staged cells (config 4 converge: 26.6 vs 19.4 ms)
         const bool blk = perm != nullptr && g->q_blocks > 0 && knobs().grid_coop == 2;
+        const bool sd_step = lg->sd && D == 3 && MODE == 0 && !blk && perm != nullptr;
         hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(blk ? static_cast<unsigned>(g->q_blocks) : nb), dim3(256),
                            blk ? kGridBlkBytes : 0, lg->stream, dev, respect,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, g->gp,
@@ -1925,9 +2055,11 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, perm,
                            blk ? g->q_start.as<int>() : nullptr, BvhView{},
                            (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr,
-                           lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>());
+                           lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>(),
+                           (sd_step ? lg->cur_s.as<double>() : nullptr), (sd_step ? lg->idx_s.as<int64_t>() : nullptr));
         ICPX_HIP(hipGetLastError());
-        lg->nn_seeded = true;  // nb_idx now holds this step's neighbours
+        if (sd_step) lg->sd_dirty = true;
+        lg->nn_seeded = true;  // nb_idx (idx_s) now holds this step's neighbours
         return ICPX_OK;
     }
     if (MODE == 0) {
@@ -2058,9 +2190,12 @@ int lg_kd_service(LargeIcp* lg, int mode, bool* stalled) {
     lg->kd_ready = true;
     hipLaunchKernelGGL(lg_kd_resume_kernel, dim3(1), dim3(64), 0, lg->stream, dev);
     ICPX_HIP(hipGetLastError());
-    ICPX_TRY(kd_launch_resolve(lg->dim, &dev->kd_count, lg->kd_list.as<uint32_t>(), mode, lg->src.as<double>(), lg->cur.as<double>(),
+    const bool sd = lg->sd && mode == 0;
+    ICPX_TRY(kd_launch_resolve(lg->dim, &dev->kd_count, lg->kd_list.as<uint32_t>(), mode, lg->src.as<double>(),
+                               sd ? lg->cur_s.as<double>() : lg->cur.as<double>(),
                                dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
-                               lg->dst.as<double>(), lg->m, lg->nb_idx.as<int64_t>(), 1024, lg->stream, lg->nb_pt.as<double>()));
+                               lg->dst.as<double>(), lg->m, sd ? lg->idx_s.as<int64_t>() : lg->nb_idx.as<int64_t>(), 1024, lg->stream,
+                               lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr));
     *stalled = true;
     return ICPX_OK;
 }
@@ -2146,6 +2281,8 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     // (ICPX_NN_GRID / ICPX_NN_BRUTE force one or the other)
     lg->use_bvh = false;
     lg->nn_seeded = false;
+    lg->sd = false;
+    lg->sd_dirty = false;
     lg->tile = lg->feature || lg->prm.nn_mode == ICPX_NN_BRUTE ||
                (lg->prm.nn_mode != ICPX_NN_GRID && lg->prm.nn_mode != ICPX_NN_BVH &&
                 static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
@@ -2188,6 +2325,16 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         } else {
             // the running cloud moves little between iterations: its initial cell order stays coherent
             ICPX_TRY(grid_sort_queries(lg->grid, lg->cur.as<double>(), n, lg->stream));
+            // sorted domain (see LargeIcp::sd); development knob ICPX_GRID_SD=0
+            if (D == 3 && lg->grid->q_perm_n == n && !(lg->prm.flags & ICPX_FLAG_FILL_MATCHES) && knobs().grid_coop != 2 &&
+                knobs().grid_sd != 0) {
+                ICPX_TRY(lg->cur_s.reserve(sizeof(double) * D * n));
+                ICPX_TRY(lg->idx_s.reserve(sizeof(int64_t) * n));
+                hipLaunchKernelGGL(lg_sd_gather_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, lg->stream,
+                                   lg->cur.as<double>(), lg->grid->q_perm.as<uint32_t>(), n, lg->cur_s.as<double>());
+                ICPX_HIP(hipGetLastError());
+                lg->sd = true;
+            }
         }
     }
     if (lg->feature) {
@@ -2332,10 +2479,24 @@ int large_transform(LargeIcp* lg, double* out) {
     return ICPX_OK;
 }
 
+// sorted domain: nb_idx / nb_cost / sel in point order, when a getter wants them
+static int sd_unpack(LargeIcp* lg) {
+    if (!lg->sd || !lg->sd_dirty) return ICPX_OK;
+    const unsigned nb = static_cast<unsigned>((lg->n + 255) / 256);
+    auto kern = lg->method == ICPX_TRIMMED ? lg_sd_unpack_kernel<ICPX_TRIMMED> : lg_sd_unpack_kernel<ICPX_VANILLA>;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, lg->stream, lg->cur_s.as<double>(), lg->idx_s.as<int64_t>(),
+                       lg->grid->q_perm.as<uint32_t>(), lg->dst.as<double>(), lg->n, lg->prm.max_distance,
+                       lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>());
+    ICPX_HIP(hipGetLastError());
+    lg->sd_dirty = false;
+    return ICPX_OK;
+}
+
 int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost) {
     // 2D only (3D is answered by the caller).  Vanilla: point order.  Trimmed: point order after
     // begin, the sorted order Trimmed::iterate leaves behind (trimmed.cpp:55-56) afterwards.
     const int64_t n = lg->n;
+    ICPX_TRY(sd_unpack(lg));
     const bool by_order = lg->dim == 2 && lg->method != ICPX_VANILLA && lg->sorted;
     DevBuf tp, tq, tc;
     int rc = tp.reserve(sizeof(int64_t) * n);
@@ -2360,6 +2521,7 @@ int large_matches(LargeIcp* lg, int64_t* point, int64_t* pair, double* cost) {
 
 int large_neighbors(LargeIcp* lg, int64_t* idx, double* dist) {
     const int64_t n = lg->n;
+    ICPX_TRY(sd_unpack(lg));
     if (idx) ICPX_HIP(hipMemcpyAsync(idx, lg->nb_idx.p, sizeof(int64_t) * n, hipMemcpyDefault, lg->stream));
     if (dist) ICPX_HIP(hipMemcpyAsync(dist, lg->nb_cost.p, sizeof(double) * n, hipMemcpyDefault, lg->stream));
     ICPX_HIP(hipStreamSynchronize(lg->stream));
