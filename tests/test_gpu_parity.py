@@ -136,15 +136,19 @@ def test_nn_against_reference_kdtree_semantics(icp, ob, scans, queen, mode):
     assert np.all(idx == 0) and np.all(np.isinf(dist))
 
 
-@pytest.mark.parametrize("path", ["fused", "large_auto", "large_grid", "large_bvh"])
+@pytest.mark.parametrize("path", ["fused", "large_auto", "large_grid", "large_bvh", "large_grid_sorted"])
 def test_kd_tie_rule_in_converge(icp, ob, path, knob):
     """The kd-tree methods follow the reference tree's tie rule inside begin / iterate / converge: clouds with planted
     ties (distinct coordinates), every iteration's neighbours, matches and transform against the oracle in canonical
     form — whose correspondences equal the real kdtree.h's on such data (test_oracle).  fused: one workgroup per
     pair (2D vanilla resolves in place; the 3D kernels stop at a tie and the take-over kernel goes on);
-    large_*: the multi-kernel path (stall, tree from the host, resolve kernel) with each correspondence engine."""
+    large_*: the multi-kernel path (tree built on the device beside the first step, resolve kernel) with each
+    correspondence engine; large_grid_sorted: enough points for the 3D grid search to run in its sorted domain and a
+    target cloud beyond the eager tree build (stall at the first tie, tree on demand)."""
     if path == "fused":
         sizes, cfg_nn = (500, 900, 120), None
+    elif path == "large_grid_sorted":
+        sizes, cfg_nn = (40000, 70000, 300), "grid"
     else:
         sizes, cfg_nn = (5000, 6000, 200), path.split("_")[1]
     # 2D vanilla: matches of begin (they never change, vanilla.cpp:80)
