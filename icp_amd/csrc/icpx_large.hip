@@ -686,27 +686,36 @@ ICPX_DEV void block_tree(F&& f, int64_t n, double* __restrict__ part, int nblk, 
             for (int v = 0; v < NV; v++) vals[k][v] = 0.0;
         }
     }
+    // level 1: the four slots of a value go through the butterfly together (xchg_sum, icpx_math.h: at xor 32 and 16 two
+    // slots share one exchange; same partners, same additions, same bits as a butterfly per slot): a lane ends with
+    // the group sum of slot kk = 2 b4 + b5 — 7 additions per value instead of 24 (the sum kernels of a 10^6-point
+    // cloud were bound by these wave-level instructions, not by memory: 38.7 -> ... us)
+    static_assert(kSlots == 4, "block_tree: four slots per thread");
+    {
+        const int kk = ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+        const int64_t g = (base >> 6) + kk * (kBlk >> 6) + wave;
 #pragma unroll
-    for (int k = 0; k < kSlots; k++) {
-        int64_t g = (base >> 6) + k * (kBlk >> 6) + wave;
-        if (g < g_total) {
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                double s = wave_sum(vals[k][v]);
-                if (lane == 0) gs[v * 64 + k * (kBlk >> 6) + wave] = s;
-            }
+        for (int v = 0; v < NV; v++) {
+            const double y0 = xchg_sum<32>(vals[0][v], vals[1][v]), y1 = xchg_sum<32>(vals[2][v], vals[3][v]);
+            double s = xchg_sum<16>(y0, y1);
+            s = s + dpp_xor<8>(s);
+            s = s + dpp_xor<4>(s);
+            s = s + dpp_xor<2>(s);
+            s = s + dpp_xor<1>(s);
+            if ((lane & 15) == 0 && g < g_total) gs[v * 64 + kk * (kBlk >> 6) + wave] = s;
         }
     }
     __syncthreads();
     if (g_total == 1) {
         if (tid < NV) st_agent(&part[tid * nblk], gs[tid * 64]);
-    } else if (wave == 0) {
-        int64_t gl = g_total - (base >> 6);  // groups in this block
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            double x = lane < gl ? gs[v * 64 + lane] : 0.0;
-            double s = wave_sum(x);
-            if (lane == 0) st_agent(&part[v * nblk + blockIdx.x], s);
+    } else {
+        // level 2: value v by wave v (NV <= 16 waves)
+        static_assert(NV <= kBlk / 64, "block_tree: one wave per value");
+        const int64_t gl = g_total - (base >> 6);  // groups in this block
+        if (wave < NV) {
+            const double x = lane < gl ? gs[wave * 64 + lane] : 0.0;
+            const double s = wave_sum(x);
+            if (lane == 0) st_agent(&part[wave * nblk + blockIdx.x], s);
         }
     }
 }
