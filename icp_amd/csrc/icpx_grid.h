@@ -101,6 +101,16 @@ __global__ void grid_bbox_kernel(const double* __restrict__ t, int64_t m, unsign
     }
 }
 
+// An upper bound of sqrt(x) for x >= 0 (inf for inf), from the f32 square root: radii that only size a cell range need
+// no f64 square root (a sequence of ~25 instructions; the seeded walk took ten of them per query).  The f32 conversion,
+// v_sqrt_f32 (1 ulp) and the conversion back err by less than 2^-22 relative in all; arguments below the f32 normal
+// range (where the conversion flushes or loses bits) get the bound sqrt(FLT_MIN).
+ICPX_DEV double sqrt_up(double x) {
+    const float xf = static_cast<float>(x);
+    const double r = static_cast<double>(__builtin_sqrtf(xf)) * 1.0000009536743164;  // (1 + 2^-20)
+    return x < 1.1754943508222875e-38 ? 1.0842021724855044e-19 : r;
+}
+
 template <int D>
 ICPX_DEV int cell_coord(const GridParams& gp, double v, int d) {
     double f = (v - gp.lo[d]) * gp.inv_h[d];
@@ -318,18 +328,18 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ r
         k1 = cell_coord<D>(gp, q[d] + r + w, d);
     };
     int z0 = 0, z1 = 0;
-    if (D == 3) range_of(2, __builtin_sqrt(best), z0, z1);
+    if (D == 3) range_of(2, sqrt_up(best), z0, z1);
     for (int z = z0; z <= z1; z++) {
         const double gz = D == 3 ? gap_of(2, z) : 0.0;
         if (gz * gz * down > best) continue;
         int y0, y1;
-        range_of(1, __builtin_sqrt(best), y0, y1);
+        range_of(1, sqrt_up(best), y0, y1);
         for (int y = y0; y <= y1; y++) {
             const double gy = gap_of(1, y);
             const double far2 = (gz * gz + gy * gy) * down;
             if (far2 > best) continue;
             int x0, x1;
-            range_of(0, __builtin_sqrt(best - far2 + best * 9.0949470177292824e-13), x0, x1);  // + 2^-40 best: the subtraction's rounding
+            range_of(0, sqrt_up(best - far2 + best * 9.0949470177292824e-13), x0, x1);  // + 2^-40 best: the subtraction's rounding
             const int row = (z * gp.g[1] + y) * gp.g[0];
             const int kb = start[row + x0], ke = start[row + x1 + 1];
             for (int k0 = kb; k0 < ke; k0 += 4) {
@@ -385,7 +395,7 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict_
         k0 = cell_coord<D>(gp, q[d] - r - w, d);
         k1 = cell_coord<D>(gp, q[d] + r + w, d);
     };
-    const double rad = __builtin_sqrt(best);
+    const double rad = sqrt_up(best);
     int z0 = 0, z1 = 0, y0, y1;
     if (D == 3) range_of(2, rad, z0, z1);
     range_of(1, rad, y0, y1);
@@ -404,7 +414,7 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict_
         const double far2 = (gz * gz + gy * gy) * down;
         in = in && !(far2 > best_in);
         int x0 = 0, x1 = 0;
-        range_of(0, __builtin_sqrt(in ? best_in - far2 + best_in * 9.0949470177292824e-13 : 0.0), x0, x1);  // as grid_ball_scan
+        range_of(0, sqrt_up(in ? best_in - far2 + best_in * 9.0949470177292824e-13 : 0.0), x0, x1);  // as grid_ball_scan
         const int row = in ? (z * gp.g[1] + y) * gp.g[0] : 0;
         kb[t] = start[row + x0];
         ke[t] = in ? start[row + x1 + 1] : kb[t];

@@ -77,7 +77,10 @@ ICPX_DEV unsigned long long kd_key(const KdView<I>& kd, const double (&q)[D], co
 template <int D>
 ICPX_DEV bool kd_tie_check(const bool valid, const double dist, const int j, const double* c,
                            const double* __restrict__ cloud, const double best, const int bidx) {
-    bool near = valid && bidx != 0x7fffffff && j != bidx && dist < __builtin_inf() && kd_near(dist, best);
+    // (a cheap necessary condition first — 4 ulps are well inside 2^-40 relative; NaN and inf fail it — so that the
+    // common far candidate costs three instructions here)
+    bool near = valid && dabs(dist - best) <= best * 9.0949470177292824e-13;
+    near = near && bidx != 0x7fffffff && j != bidx && dist < __builtin_inf() && kd_near(dist, best);
     if (near && dist == best && cloud != nullptr) {
         bool same = true;
 #pragma unroll

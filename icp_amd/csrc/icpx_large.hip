@@ -382,8 +382,9 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
             for (int d = 0; d < D; d++) cur_s[k * D + d] = q[d];
         }
         bool searched = false;
+        int64_t sidx = -1;
         if (seed_tgt) {
-            const int64_t sidx = idx_s[k];
+            sidx = idx_s[k];
             bool ok = gp.m > 0;
             double df = seed_tgt[sidx * D] - q[0];
             double d2s = df * df;
@@ -403,9 +404,13 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
             }
         }
         if (!searched) grid_query<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
-        idx_s[k] = bi;
+        // nb_pt[i] always holds the coordinates of target idx_s[k] (the resolve kernel keeps that too): a query whose
+        // neighbour is the one of the previous step — most of them, late in a converge — has nothing to gather or scatter
+        if (static_cast<int64_t>(bi) != sidx) {
+            idx_s[k] = bi;
 #pragma unroll
-        for (int d = 0; d < D; d++) nb_pt[i * D + d] = cloud[static_cast<int64_t>(bi) * D + d];
+            for (int d = 0; d < D; d++) nb_pt[i * D + d] = cloud[static_cast<int64_t>(bi) * D + d];
+        }
         if (TIES && tie) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(k);
         return;
     }
