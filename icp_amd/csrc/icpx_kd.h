@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kKdResolveThreads)
 kd_resolve_kernel(const int* __restrict__ count, const uint32_t* __restrict__ list, const int mode,
                   const double* __restrict__ src, const double* __restrict__ cur, const double* __restrict__ xf,
                   const KdView<uint32_t> kd, int64_t* __restrict__ nb_idx, double* __restrict__ nb_pt,
-                  const uint32_t* __restrict__ pt_perm) {
+                  const uint32_t* __restrict__ pt_perm, double* __restrict__ pt_sorted) {
     __shared__ unsigned long long s_key[kKdResolveThreads / 64];
     __shared__ int s_idx[kKdResolveThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -216,7 +216,11 @@ kd_resolve_kernel(const int* __restrict__ count, const uint32_t* __restrict__ li
             if (nb_pt) {  // (the multi-kernel path keeps the matched target's coordinates beside its index)
                 const int64_t at = pt_perm ? static_cast<int64_t>(pt_perm[i]) : i;  // (sorted domain: i is a position of the query order)
 #pragma unroll
-                for (int d = 0; d < D; d++) nb_pt[at * D + d] = kd.pts[static_cast<int64_t>(lowest) * D + d];
+                for (int d = 0; d < D; d++) {
+                    const double v = kd.pts[static_cast<int64_t>(lowest) * D + d];
+                    nb_pt[at * D + d] = v;
+                    if (pt_sorted) pt_sorted[i * D + d] = v;  // (sorted domain: the copy in query order)
+                }
             }
         }
     }

@@ -146,7 +146,7 @@ struct LargeIcp {
     // to `cur` themselves and recompute the selection from the two points.  nb_idx / nb_cost / sel in point order are
     // written on demand (sd_unpack).
     bool sd = false, sd_dirty = false;
-    DevBuf cur_s, idx_s;
+    DevBuf cur_s, idx_s, pt_s;  // pt_s: the previous neighbour's coordinates in query order (the seed without a gather)
     // trimmed ICP2: sort of (cost bits, point) -> matches order of trimmed.cpp:55-56
     DevBuf sort_keys, sort_iota, sort_order, sort_tmp;
     size_t sort_tmp_bytes = 0;
@@ -283,7 +283,8 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
              double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh,
              const double* __restrict__ seed_tgt, const double* __restrict__ cloud, uint32_t* __restrict__ kd_list,
-             double* __restrict__ nb_pt, double* __restrict__ cur_s = nullptr, int64_t* __restrict__ idx_s = nullptr) {
+             double* __restrict__ nb_pt, double* __restrict__ cur_s = nullptr, int64_t* __restrict__ idx_s = nullptr,
+             double* __restrict__ pt_s = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     // the kd-tree methods follow the reference tree's tie rule (icpx_kd.h): flagged queries go on kd_list
     constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
@@ -386,11 +387,12 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         if (seed_tgt) {
             sidx = idx_s[k];
             bool ok = gp.m > 0;
-            double df = seed_tgt[sidx * D] - q[0];
+            // (pt_s[k]: the coordinates of target idx_s[k], kept in query order — streamed, where seed_tgt[sidx] is a gather)
+            double df = pt_s[k * D] - q[0];
             double d2s = df * df;
 #pragma unroll
             for (int d = 1; d < D; d++) {
-                df = seed_tgt[sidx * D + d] - q[d];
+                df = pt_s[k * D + d] - q[d];
                 d2s = d2s + df * df;
             }
 #pragma unroll
@@ -409,7 +411,11 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         if (static_cast<int64_t>(bi) != sidx) {
             idx_s[k] = bi;
 #pragma unroll
-            for (int d = 0; d < D; d++) nb_pt[i * D + d] = cloud[static_cast<int64_t>(bi) * D + d];
+            for (int d = 0; d < D; d++) {
+                const double v = cloud[static_cast<int64_t>(bi) * D + d];
+                nb_pt[i * D + d] = v;
+                pt_s[k * D + d] = v;
+            }
         }
         if (TIES && tie) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(k);
         return;
@@ -1827,16 +1833,17 @@ int kd_debug_tree(int dim, const double* d_t, int64_t m, uint32_t* h_node, hipSt
 
 int kd_launch_resolve(int dim, const int* d_count, const uint32_t* d_list, int mode, const double* src, const double* cur,
                       const double* xf, const uint32_t* d_node, const uint32_t* d_pos, const double* d_t, int64_t m,
-                      int64_t* d_idx, int blocks, hipStream_t stream, double* d_pt = nullptr, const uint32_t* d_perm = nullptr) {
+                      int64_t* d_idx, int blocks, hipStream_t stream, double* d_pt = nullptr, const uint32_t* d_perm = nullptr,
+                      double* d_pt_sorted = nullptr) {
     KdView<uint32_t> kd;
     kd.node = d_node;
     kd.pos = d_pos;
     kd.pts = d_t;
     kd.m = static_cast<int>(m);
     if (dim == 2)
-        hipLaunchKernelGGL(kd_resolve_kernel<2>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt, d_perm);
+        hipLaunchKernelGGL(kd_resolve_kernel<2>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt, d_perm, d_pt_sorted);
     else
-        hipLaunchKernelGGL(kd_resolve_kernel<3>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt, d_perm);
+        hipLaunchKernelGGL(kd_resolve_kernel<3>, dim3(blocks), dim3(kKdResolveThreads), 0, stream, d_count, d_list, mode, src, cur, xf, kd, d_idx, d_pt, d_perm, d_pt_sorted);
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1904,7 +1911,7 @@ void large_destroy(LargeIcp* lg) {
     if (lg->kd_ev_cloud) (void)hipEventDestroy(lg->kd_ev_cloud);
     if (lg->kd_ev_tree) (void)hipEventDestroy(lg->kd_ev_tree);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
-                      &lg->cntp, &lg->dev, &lg->nb_pt, &lg->cur_s, &lg->idx_s, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
+                      &lg->cntp, &lg->dev, &lg->nb_pt, &lg->cur_s, &lg->idx_s, &lg->pt_s, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
                       &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree, &lg->kd_scratch})
         b->release();
     grid_destroy(lg->grid);
@@ -2028,7 +2035,7 @@ int enqueue_kd_resolve(LargeIcp* lg) {
                              sd ? lg->cur_s.as<double>() : lg->cur.as<double>(),
                              dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
                              lg->dst.as<double>(), lg->m, sd ? lg->idx_s.as<int64_t>() : lg->nb_idx.as<int64_t>(), 1024, lg->stream,
-                             lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr);
+                             lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr, sd ? lg->pt_s.as<double>() : nullptr);
 }
 
 template <int D, int METHOD, int MODE>
@@ -2070,7 +2077,8 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
                            blk ? g->q_start.as<int>() : nullptr, BvhView{},
                            (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr,
                            lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>(),
-                           (sd_step ? lg->cur_s.as<double>() : nullptr), (sd_step ? lg->idx_s.as<int64_t>() : nullptr));
+                           (sd_step ? lg->cur_s.as<double>() : nullptr), (sd_step ? lg->idx_s.as<int64_t>() : nullptr),
+                           (sd_step ? lg->pt_s.as<double>() : nullptr));
         ICPX_HIP(hipGetLastError());
         if (sd_step) lg->sd_dirty = true;
         lg->nn_seeded = true;  // nb_idx (idx_s) now holds this step's neighbours
@@ -2209,7 +2217,7 @@ int lg_kd_service(LargeIcp* lg, int mode, bool* stalled) {
                                sd ? lg->cur_s.as<double>() : lg->cur.as<double>(),
                                dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
                                lg->dst.as<double>(), lg->m, sd ? lg->idx_s.as<int64_t>() : lg->nb_idx.as<int64_t>(), 1024, lg->stream,
-                               lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr));
+                               lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr, sd ? lg->pt_s.as<double>() : nullptr));
     *stalled = true;
     return ICPX_OK;
 }
@@ -2344,6 +2352,7 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
                 knobs().grid_sd != 0) {
                 ICPX_TRY(lg->cur_s.reserve(sizeof(double) * D * n));
                 ICPX_TRY(lg->idx_s.reserve(sizeof(int64_t) * n));
+                ICPX_TRY(lg->pt_s.reserve(sizeof(double) * D * n));
                 hipLaunchKernelGGL(lg_sd_gather_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, lg->stream,
                                    lg->cur.as<double>(), lg->grid->q_perm.as<uint32_t>(), n, lg->cur_s.as<double>());
                 ICPX_HIP(hipGetLastError());
