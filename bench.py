@@ -463,7 +463,38 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
     # time of 50 iterations, not of a converged registration
     ex["c4_converge_stopped_by"] = ("max_iterations (%d): not converged" % MAX_ITER) if r4.iteration_count >= MAX_ITER \
         else "transform tolerance"
+    # roofline of one iteration of this path (HBM): what an iteration must move at least — the running cloud read and
+    # written (48 B per point), the matched target's coordinates and index written for the sums (32 B per point), the
+    # target cloud read once (24 B per target); the examined grid records (L2 mostly) are on top and not counted
+    it_bytes = len(src) * (48 + 32) + len(tgt) * 24
+    it_s = dt4 / max(1, r4.iteration_count)
+    ex["c4_converge"] = {"ms_per_iteration": it_s * 1e3, "algorithmic_bytes_per_iteration": it_bytes,
+                         "roofline": {"bound": "hbm", "achieved": it_bytes / it_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                      "frac": it_bytes / it_s / 1e9 / 8000.0,
+                                      "from_profile": newest_profile("_c4_converge_kernel_stats.csv"),
+                                      "note": "per iteration: lg_nn_kernel (seeded grid walk in the sorted domain, a chain of "
+                                              "dependent L2 round trips) ~3/4 of the time, the two sum kernels the rest"}}
+    # configs 2 and 3 (one pair each): the correspondence work of the path is brute force in the SURVEY 8(d) model,
+    # 8 flops per (query, target) and correspondence step, against the f64 FMA peak — a latency figure, not a
+    # throughput one: one scan-sized pair occupies one compute unit of 256
+    f2 = 8.0 * len(a) * len(b) * (ex["c2_scan1_iterations"] + 1)
+    ex["c2_scan1_roofline"] = {"bound": "valu_fp64", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+                               "achieved": f2 / (ex["c2_scan1_trimmed_converge_ms"] * 1e-3) / 1e12,
+                               "frac": f2 / (ex["c2_scan1_trimmed_converge_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                               "model": "8 flops x n x m x (iterations + 1) correspondence steps"}
+    f3 = 8.0 * len(qt) * len(q) * ex["c3_queen_iterations"]
+    ex["c3_queen_roofline"] = {"bound": "valu_fp64", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+                               "achieved": f3 / (ex["c3_queen_vanilla3d_converge_ms"] * 1e-3) / 1e12,
+                               "frac": f3 / (ex["c3_queen_vanilla3d_converge_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                               "from_profile": newest_profile("_queen_kernel_stats.csv"),
+                               "model": "8 flops x n x m x iterations (tiled brute force with the f32 candidate filter)"}
     return ex
+
+
+def newest_profile(suffix):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
+    return ("profiles/" + os.path.basename(files[-1])) if files else None
 
 
 def extras_config5(torch, icp_amd, workload, sh, local_rank):
