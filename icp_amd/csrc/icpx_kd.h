@@ -49,23 +49,46 @@ struct KdView {
 
 // Pre-order key of target t for query q: two bits per level from the root — 0 this node, 1 the child on the query's
 // side (kdtree.h:146: left iff q[axis] < node[axis]), 2 the other child.  Smaller key = visited earlier.
+// The path from the root to t's node depends on t's position alone (which side of every median it lies on), so the
+// medians of up to eight levels are known before anything is loaded: their nodes and split coordinates are fetched
+// as two rounds of independent loads instead of two dependent loads per level (the resolve kernel of a cloud with many
+// ties was a chain of those: 28 round trips per key).
 template <int D, typename I>
 ICPX_DEV unsigned long long kd_key(const KdView<I>& kd, const double (&q)[D], const int t) {
     const int P = static_cast<int>(kd.pos[t]);
     int lo = 0, hi = kd.m, axis = 0;
     unsigned long long k = 0;
-    for (int depth = 0; depth < 31; depth++) {
-        const int mid = lo + ((hi - lo - 1) >> 1);
-        if (P == mid) break;
-        const double c = kd.pts[static_cast<int64_t>(kd.node[mid]) * D + axis];
-        double qa = q[0];
+    bool fin = false;
+    for (int depth = 0; depth < 32 && !fin; depth += 8) {
+        int mids[8], axes[8];
+        bool on[8];
 #pragma unroll
-        for (int d = 1; d < D; d++) qa = axis == d ? q[d] : qa;
-        const bool near_left = qa < c, go_left = P < mid;
-        k |= static_cast<unsigned long long>(go_left == near_left ? 1 : 2) << (60 - 2 * depth);
-        if (go_left) hi = mid;
-        else lo = mid + 1;
-        axis = axis + 1 == D ? 0 : axis + 1;
+        for (int u = 0; u < 8; u++) {
+            const int mid = lo + ((hi - lo - 1) >> 1);
+            fin = fin || P == mid || depth + u >= 31;
+            on[u] = !fin;
+            mids[u] = mid;
+            axes[u] = axis;
+            if (on[u]) {
+                if (P < mid) hi = mid;
+                else lo = mid + 1;
+                axis = axis + 1 == D ? 0 : axis + 1;
+            }
+        }
+        int64_t nd[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) nd[u] = on[u] ? static_cast<int64_t>(kd.node[mids[u]]) : 0;
+        double c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = on[u] ? kd.pts[nd[u] * D + axes[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            double qa = q[0];
+#pragma unroll
+            for (int d = 1; d < D; d++) qa = axes[u] == d ? q[d] : qa;
+            const bool near_left = qa < c[u], go_left = P < mids[u];
+            if (on[u]) k |= static_cast<unsigned long long>(go_left == near_left ? 1 : 2) << (60 - 2 * (depth + u));
+        }
     }
     return k;
 }
@@ -127,99 +150,148 @@ ICPX_DEV void kd_query_of(const int mode, const double* __restrict__ src, const 
 }
 
 constexpr int kKdResolveThreads = 256;
+constexpr int kKdResolveBatch = 8;  // flagged queries a workgroup takes through the cloud together
 
 // count: device word (number of flagged queries); nb_idx: in = the (d2, index) minimum's target, out = the rule's;
-// nb_pt (may be null): out = that target's coordinates.
-// nb_d2 (may be null): receives nothing new (all tied targets share sqrt(d2)); the minimum's d2 is recomputed here.
+// nb_pt (may be null): out = that target's coordinates (at pt_perm[i] when given), pt_sorted (may be null): a second
+// copy at i.  A workgroup takes kKdResolveBatch flagged queries through the cloud together.  (queen.ply flags 2 989 of
+// 10 720 queries at its first step, nearly all of them for coincident duplicates of the winner that the in-tile
+// detection cannot tell from a tie: 84 us.  Measured and dropped: eight targets' loads in flight per trip (112 us: the
+// unrolled body with a copy of kd_key behind every test outgrows the instruction cache) and kd_key as a real call (154).)
 template <int D>
 __global__ void __launch_bounds__(kKdResolveThreads)
 kd_resolve_kernel(const int* __restrict__ count, const uint32_t* __restrict__ list, const int mode,
                   const double* __restrict__ src, const double* __restrict__ cur, const double* __restrict__ xf,
                   const KdView<uint32_t> kd, int64_t* __restrict__ nb_idx, double* __restrict__ nb_pt,
                   const uint32_t* __restrict__ pt_perm, double* __restrict__ pt_sorted) {
-    __shared__ unsigned long long s_key[kKdResolveThreads / 64];
-    __shared__ int s_idx[kKdResolveThreads / 64];
+    constexpr int W = kKdResolveThreads / 64, B = kKdResolveBatch;
+    __shared__ unsigned long long s_key[B][W];
+    __shared__ int s_idx[B][W];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int W = kKdResolveThreads / 64;
     const int total = *count;
-    for (int e = blockIdx.x; e < total; e += gridDim.x) {
-        const int64_t i = list[e];
-        double q[D];
-        kd_query_of<D>(mode, src, cur, xf, i, q);
-        // the minimal d2 (the engines' answer, recomputed: nb_idx names a target that attains it)
-        const int64_t b0 = nb_idx[i];
-        double best = 0.0;
+    for (int e0 = blockIdx.x * B; e0 < total; e0 += gridDim.x * B) {
+        const int nq = total - e0 < B ? total - e0 : B;  // (uniform)
+        double q[B][D], best[B], s[B];
+        int64_t qi[B];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            const double df = kd.pts[b0 * D + d] - q[d];
-            best = d == 0 ? df * df : best + df * df;
-        }
-        if (!(best < __builtin_inf())) continue;  // (uniform) nothing finite: the (d2, index) convention stands
-        const double s = __builtin_sqrt(best);
-        unsigned long long mk = ~0ull;
-        int mi = 0x7fffffff;
-        for (int j = tid; j < kd.m; j += kKdResolveThreads) {
-            double df = kd.pts[static_cast<int64_t>(j) * D] - q[0];
-            double acc = df * df;
+        for (int b = 0; b < B; b++) {
+            qi[b] = list[e0 + (b < nq ? b : 0)];
+            kd_query_of<D>(mode, src, cur, xf, qi[b], q[b]);
+            // the minimal d2 (the engines' answer, recomputed: nb_idx names a target that attains it)
+            const int64_t b0 = nb_idx[qi[b]];
+            double acc = 0.0;
 #pragma unroll
-            for (int d = 1; d < D; d++) {
-                df = kd.pts[static_cast<int64_t>(j) * D + d] - q[d];
-                acc = acc + df * df;
+            for (int d = 0; d < D; d++) {
+                const double df = kd.pts[b0 * D + d] - q[b][d];
+                acc = d == 0 ? df * df : acc + df * df;
             }
-            if (kd_near(acc, best) && __builtin_sqrt(acc) == s) {
-                const unsigned long long k = kd_key<D, uint32_t>(kd, q, j);
-                if (k < mk) {
-                    mk = k;
-                    mi = j;
+            // (nothing finite, or a slot beyond the batch's end: NaN compares false everywhere below)
+            best[b] = (b < nq && acc < __builtin_inf()) ? acc : __builtin_nan("");
+            s[b] = __builtin_sqrt(best[b]);
+        }
+        unsigned long long mk[B];
+        int mi[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            mk[b] = ~0ull;
+            mi[b] = 0x7fffffff;
+        }
+        for (int j = tid; j < kd.m; j += kKdResolveThreads) {
+            double t[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) t[d] = kd.pts[static_cast<int64_t>(j) * D + d];
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                double df = t[0] - q[b][0];
+                double acc = df * df;
+#pragma unroll
+                for (int d = 1; d < D; d++) {
+                    df = t[d] - q[b][d];
+                    acc = acc + df * df;
+                }
+                if (dabs(acc - best[b]) <= best[b] * 9.0949470177292824e-13 && kd_near(acc, best[b]) && __builtin_sqrt(acc) == s[b]) {
+                    const unsigned long long k = kd_key<D, uint32_t>(kd, q[b], j);
+                    if (k < mk[b]) {
+                        mk[b] = k;
+                        mi[b] = j;
+                    }
                 }
             }
         }
+        __syncthreads();  // (the previous batch's reads of the shared words are done)
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const unsigned long long ok = __shfl_xor(mk, o);
-            const int oi = __shfl_xor(mi, o);
-            const bool take = ok < mk;
-            mk = take ? ok : mk;
-            mi = take ? oi : mi;
-        }
-        __syncthreads();  // (the previous entry's reads of the shared words are done)
-        if (lane == 0) {
-            s_key[wave] = mk;
-            s_idx[wave] = mi;
+        for (int b = 0; b < B; b++) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const unsigned long long ok = __shfl_xor(mk[b], o);
+                const int oi = __shfl_xor(mi[b], o);
+                const bool take = ok < mk[b];
+                mk[b] = take ? ok : mk[b];
+                mi[b] = take ? oi : mi[b];
+            }
+            if (lane == 0) {
+                s_key[b][wave] = mk[b];
+                s_idx[b][wave] = mi[b];
+            }
         }
         __syncthreads();
-        for (int w = 0; w < W; w++) {
-            const bool take = s_key[w] < mk;
-            mk = take ? s_key[w] : mk;
-            mi = take ? s_idx[w] : mi;
+        double w[B][D];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            for (int ww = 0; ww < W; ww++) {
+                const bool take = s_key[b][ww] < mk[b];
+                mk[b] = take ? s_key[b][ww] : mk[b];
+                mi[b] = take ? s_idx[b][ww] : mi[b];
+            }
+            // (mi == 0x7fffffff: no finite minimum, or beyond the batch: nothing to do for this slot)
+            const int64_t wj = mi[b] == 0x7fffffff ? 0 : mi[b];
+#pragma unroll
+            for (int d = 0; d < D; d++) w[b][d] = kd.pts[wj * D + d];
         }
-        if (mi == 0x7fffffff) continue;  // (uniform; cannot happen: the minimum itself is in the tied set)
-        // the lowest index among the targets coincident with the winner
-        double w[D];
+        // the lowest index among the targets coincident with each winner
+        int lowest[B];
 #pragma unroll
-        for (int d = 0; d < D; d++) w[d] = kd.pts[static_cast<int64_t>(mi) * D + d];
-        int lowest = mi;
-        for (int j = tid; j < kd.m && j < mi; j += kKdResolveThreads) {
-            bool same = true;
+        for (int b = 0; b < B; b++) lowest[b] = mi[b];
+        for (int j = tid; j < kd.m; j += kKdResolveThreads) {
+            double t[D];
 #pragma unroll
-            for (int d = 0; d < D; d++) same = same && kd.pts[static_cast<int64_t>(j) * D + d] == w[d];
-            lowest = (same && j < lowest) ? j : lowest;
+            for (int d = 0; d < D; d++) t[d] = kd.pts[static_cast<int64_t>(j) * D + d];
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                bool same = true;
+#pragma unroll
+                for (int d = 0; d < D; d++) same = same && t[d] == w[b][d];
+                lowest[b] = (same && j < lowest[b]) ? j : lowest[b];
+            }
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) lowest = min(lowest, __shfl_xor(lowest, o));
         __syncthreads();
-        if (lane == 0) s_idx[wave] = lowest;
-        __syncthreads();
-        for (int ww = 0; ww < W; ww++) lowest = min(lowest, s_idx[ww]);
-        if (tid == 0) {
-            nb_idx[i] = lowest;
-            if (nb_pt) {  // (the multi-kernel path keeps the matched target's coordinates beside its index)
-                const int64_t at = pt_perm ? static_cast<int64_t>(pt_perm[i]) : i;  // (sorted domain: i is a position of the query order)
 #pragma unroll
-                for (int d = 0; d < D; d++) {
-                    const double v = kd.pts[static_cast<int64_t>(lowest) * D + d];
-                    nb_pt[at * D + d] = v;
-                    if (pt_sorted) pt_sorted[i * D + d] = v;  // (sorted domain: the copy in query order)
+        for (int b = 0; b < B; b++) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) lowest[b] = min(lowest[b], __shfl_xor(lowest[b], o));
+            if (lane == 0) s_idx[b][wave] = lowest[b];
+        }
+        __syncthreads();
+        if (tid < nq) {
+            // (one thread per query of the batch; runtime index into the register arrays through a small switch)
+            int low = 0x7fffffff;
+            int64_t i = 0;
+#pragma unroll
+            for (int b = 0; b < B; b++)
+                if (b == tid) {
+                    for (int ww = 0; ww < W; ww++) low = min(low, s_idx[b][ww]);
+                    i = qi[b];
+                }
+            if (low != 0x7fffffff) {
+                nb_idx[i] = low;
+                if (nb_pt) {  // (the multi-kernel path keeps the matched target's coordinates beside its index)
+                    const int64_t at = pt_perm ? static_cast<int64_t>(pt_perm[i]) : i;  // (sorted domain: i is a position of the query order)
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
+                        const double v = kd.pts[static_cast<int64_t>(low) * D + d];
+                        nb_pt[at * D + d] = v;
+                        if (pt_sorted) pt_sorted[i * D + d] = v;  // (sorted domain: the copy in query order)
+                    }
                 }
             }
         }

@@ -2309,19 +2309,21 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
                (lg->prm.nn_mode != ICPX_NN_GRID && lg->prm.nn_mode != ICPX_NN_BVH &&
                 static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
     if (lg->tile) {
-        const int64_t most = (m + kTileMinSplit - 1) / kTileMinSplit;  // splits of at least kTileMinSplit targets
+        const int64_t min_split = knobs().tile_min.load() > 0 ? knobs().tile_min.load() : kTileMinSplit;  // development knob ICPX_TILE_MIN
+        const int64_t most = (m + min_split - 1) / min_split;  // splits of at least that many targets
         // queries per thread: four, unless the cloud then gives fewer than ~3 workgroups per CU even with the most
         // splits — one wave per SIMD leaves every load of the search exposed (queen, 10 720 points: 231 workgroups,
         // 1.43 ms; 882 workgroups with one query per thread, 1.21 ms); ICPX_TILE_QPT fixes it (development)
+        const int64_t want_wgs = knobs().tile_wgs.load() > 0 ? knobs().tile_wgs.load() : 768;  // development knob ICPX_TILE_WGS
         lg->tile_qpt = kTileQpt;
         if (kTileQptAuto)
             for (int qpt = 4; qpt >= 1; qpt >>= 1) {
                 lg->tile_qpt = qpt;
-                if (((n + kTileThreads * qpt - 1) / (kTileThreads * qpt)) * most >= 768) break;
+                if (((n + kTileThreads * qpt - 1) / (kTileThreads * qpt)) * most >= want_wgs) break;
             }
         const int64_t tile_queries = static_cast<int64_t>(kTileThreads) * lg->tile_qpt;
         const int64_t ntq = (n + tile_queries - 1) / tile_queries;
-        int64_t splits = (768 + ntq - 1) / ntq;                       // aim at ~3 workgroups per CU
+        int64_t splits = (want_wgs + ntq - 1) / ntq;                  // aim at ~3 workgroups per CU
         if (splits > most) splits = most;
         if (splits < 1) splits = 1;
         int64_t len = ((m + splits - 1) / splits + 3) & ~int64_t(3);
