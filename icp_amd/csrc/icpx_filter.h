@@ -462,8 +462,18 @@ ICPX_DEV void coop_rescan(bool flag, const double (&q)[D], const float (&q2)[D],
             double ob = __shfl_xor(bb, o);
             int oi = __shfl_xor(bi, o);
             bool take = ob < bb || (ob == bb && oi < bi);
-            // (two lanes' minima within the tie range: flagged without the coincidence test of nn_take)
-            if (TIES) lt |= (oi != 0x7fffffff && bi != 0x7fffffff && oi != bi && ob < __builtin_inf() && kd_near(ob, bb)) ? 1 : 0;
+            // two lanes' minima within the tie range: a tie unless the two targets coincide (a cloud with duplicate
+            // points — queen.ply has 1 956 — would flag every query whose neighbour has a twin)
+            if (TIES) {
+                bool near = oi != 0x7fffffff && bi != 0x7fffffff && oi != bi && ob < __builtin_inf() && kd_near(ob, bb);
+                if (near && ob == bb && L.cloud != nullptr) {
+                    bool same = true;
+#pragma unroll
+                    for (int d = 0; d < D; d++) same = same && L.cloud[static_cast<int64_t>(oi) * D + d] == L.cloud[static_cast<int64_t>(bi) * D + d];
+                    near = !same;
+                }
+                lt |= near ? 1 : 0;
+            }
             bb = take ? ob : bb;
             bi = take ? oi : bi;
         }
