@@ -127,7 +127,7 @@ ICPX_DEV void nn_take(const bool valid, const double dist, const int j, const do
 
 // Resolution of flagged queries, one workgroup per query, scanning the whole cloud (multi-kernel path and the
 // stand-alone query: flagged queries are rare, and this needs nothing from the engine that found the minimum).
-// list[0..count): query indices.  MODE as lg_nn_kernel (0: queries = cur, 1: src, 2 / 3: transform * src).
+// list[0..count): query indices.  MODE as lg_nn_kernel (0: queries = cur, 1: src, 2 / 3: transform * src); 4: xf * cur.
 template <int D>
 ICPX_DEV void kd_query_of(const int mode, const double* __restrict__ src, const double* __restrict__ cur, const double* xf,
                           const int64_t i, double (&q)[D]) {
@@ -138,13 +138,14 @@ ICPX_DEV void kd_query_of(const int mode, const double* __restrict__ src, const 
 #pragma unroll
         for (int d = 0; d < D; d++) q[d] = src[i * D + d];
     } else {
+        // 2 / 3: xf * src; 4: xf * cur (the tiled 3D search: xf = the step, the cloud not yet stepped)
         Xf<D> X;
 #pragma unroll
         for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = xf[e];
         const XfRows<D> xr = xf_rows<D>(X);
         double p[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) p[d] = src[i * D + d];
+        for (int d = 0; d < D; d++) p[d] = mode == 4 ? cur[i * D + d] : src[i * D + d];
         xf_apply<D>(xr, p, q);
     }
 }

@@ -495,25 +495,7 @@ __global__ void lg_apply_guess_kernel(const double* __restrict__ guess, const do
     cur[i * 3 + 2] = q[2];
 }
 
-template <int D>
-__global__ void lg_step_kernel(LargeDev* dev, int respect_done, double* __restrict__ cur, int64_t n) {
-    if (lg_skip(dev, respect_done)) return;
-    int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // c = T * c with the step the previous iteration produced (identity after begin), vanilla_3d.cpp:91
-    Xf<D> S;
-#pragma unroll
-    for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
-    XfRows<D> sr = xf_rows<D>(S);
-    double c[D], q[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
-    xf_apply<D>(sr, c, q);
-#pragma unroll
-    for (int d = 0; d < D; d++) cur[i * D + d] = q[d];
-}
-
-// MODE as in lg_nn_kernel (0: queries = running cloud, already stepped; 1: untransformed source;
+// MODE as in lg_nn_kernel (0: queries = step * running cloud, computed here; 1: untransformed source;
 // 2: transform * source)
 template <int D, int MODE, int QPT>
 __global__ void __launch_bounds__(kTileThreads)
@@ -549,10 +531,12 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     const int64_t qbase = static_cast<int64_t>(blockIdx.x) * (kTileThreads * QPT);
     const bool seeded = dev->nn_valid != 0;
     XfRows<D> xr;
-    if (MODE == 2 || MODE == 3) {
+    if (MODE == 2 || MODE == 3 || MODE == 0) {
+        // MODE 0: c = T * c with the step the previous iteration produced (identity after begin), vanilla_3d.cpp:91 — every
+        // split's workgroup computes it from the unstepped cloud (lg_sum1 writes the stepped one behind this kernel)
         Xf<D> X;
 #pragma unroll
-        for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+        for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = MODE == 0 ? dev->step[e] : dev->st.transform[e];
         xr = xf_rows<D>(X);
     }
 #pragma unroll
@@ -562,7 +546,7 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
         double pnt[D];
 #pragma unroll
         for (int d = 0; d < D; d++) pnt[d] = valid ? (MODE == 0 ? cur[i * D + d] : src[i * D + d]) : 0.0;
-        if (MODE == 2 || MODE == 3) {
+        if (MODE == 2 || MODE == 3 || MODE == 0) {
             xf_apply<D>(xr, pnt, q[k]);  // a_current = transform * a, trimmed.cpp:40
         } else {
 #pragma unroll
@@ -1026,7 +1010,10 @@ __global__ void __launch_bounds__(kBlk)
 lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
                const double* __restrict__ nb_pt, int64_t n, const double* __restrict__ nb_cost,
                const uint8_t* __restrict__ sel, double* __restrict__ part, int* __restrict__ cntp, int nblk, int groups,
-               int* hflags, int sd, double max_distance) {
+               int* hflags, int sd_flags, double max_distance) {
+    // sd_flags (3D): bit 0 — the cloud in point order takes the step here (the correspondence kernel worked on a
+    // stepped copy of its own, or stepped the points on the fly); bit 1 — the selection comes from the two points
+    const bool sd_step = (sd_flags & 1) != 0, sd = (sd_flags & 2) != 0;
     __shared__ double gs[(2 * D + 1) * 64];
     __shared__ int wcnt[kBlk / 64];
     __shared__ int s_last;
@@ -1040,7 +1027,7 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
     // sorted domain (LargeIcp::sd, 3D): the correspondence kernel stepped its own copy of the cloud; the cloud in point
     // order takes the same step here (c = T * c, vanilla_3d.cpp:91), and the selection comes from the two points
     XfRows<D> sr;
-    if (D == 3 && sd) {
+    if (D == 3 && sd_step) {
         Xf<D> S;
 #pragma unroll
         for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
@@ -1056,7 +1043,7 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
             } else {
 #pragma unroll
                 for (int d = 0; d < D; d++) c[d] = cur[i * D + d];
-                if (sd) {
+                if (sd_step) {
 #pragma unroll
                     for (int d = 0; d < D; d++) p[d] = c[d];
                     xf_apply<D>(sr, p, c);
@@ -1116,7 +1103,8 @@ __global__ void __launch_bounds__(kBlk)
 lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                const double* __restrict__ nb_pt, int64_t n, const uint8_t* __restrict__ sel, double* __restrict__ part,
                int nblk, int groups, double n_points, int check, icpx_criteria crit, double clock_to_s, double host_elapsed_s,
-               int* hflags, int sd, double max_distance) {
+               int* hflags, int sd_flags, double max_distance) {
+    const bool sd = (sd_flags & 2) != 0;
     __shared__ double gs[D * D * 64];
     __shared__ int s_last;
     if (lg_skip(dev, respect_done)) return;
@@ -1928,6 +1916,9 @@ inline icpx_criteria zero_criteria() {
     return c;
 }
 
+// flags of the sum kernels (lg_sum1_kernel): sorted domain = both; tiled 3D search = the step only
+inline int lg_sd_flags(const LargeIcp* lg) { return lg->sd ? 3 : ((lg->dim == 3 && lg->tile) ? 1 : 0); }
+
 template <int D, int METHOD>
 int enqueue_sums(LargeIcp* lg, int respect_done, bool second, int check = 0, const icpx_criteria* crit = nullptr,
                  double host_elapsed_s = 0.0) {
@@ -1939,7 +1930,7 @@ int enqueue_sums(LargeIcp* lg, int respect_done, bool second, int check = 0, con
         hipLaunchKernelGGL((lg_sum1_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->nb_pt.as<double>(), lg->n,
                            lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(),
-                           lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups, lg->poll_dev, lg->sd ? 1 : 0,
+                           lg->part.as<double>(), lg->cntp.as<int>(), nblk, groups, lg->poll_dev, lg_sd_flags(lg),
                            lg->prm.max_distance);
         ICPX_HIP(hipGetLastError());
     } else {
@@ -1947,7 +1938,7 @@ int enqueue_sums(LargeIcp* lg, int respect_done, bool second, int check = 0, con
         hipLaunchKernelGGL((lg_sum2_kernel<D, METHOD>), grid, block, 0, lg->stream, dev, respect_done,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->nb_pt.as<double>(), lg->n,
                            lg->sel.as<uint8_t>(), lg->part.as<double>(), nblk, groups, static_cast<double>(lg->n), check,
-                           crit ? *crit : zero_criteria(), lg->clock_to_s, host_elapsed_s, lg->poll_dev, lg->sd ? 1 : 0,
+                           crit ? *crit : zero_criteria(), lg->clock_to_s, host_elapsed_s, lg->poll_dev, lg_sd_flags(lg),
                            lg->prm.max_distance);
         ICPX_HIP(hipGetLastError());
     }
@@ -2031,9 +2022,11 @@ int enqueue_kd_resolve(LargeIcp* lg) {
     }
     // (sorted domain: the list holds positions of the query order; queries and neighbours live in cur_s / idx_s)
     const bool sd = lg->sd && MODE == 0;
-    return kd_launch_resolve(D, &dev->kd_count, lg->kd_list.as<uint32_t>(), MODE, lg->src.as<double>(),
+    // (tiled 3D search: its queries are step * cur, the cloud itself is stepped later, by lg_sum1)
+    const bool on_the_fly = D == 3 && MODE == 0 && lg->tile;
+    return kd_launch_resolve(D, &dev->kd_count, lg->kd_list.as<uint32_t>(), on_the_fly ? 4 : MODE, lg->src.as<double>(),
                              sd ? lg->cur_s.as<double>() : lg->cur.as<double>(),
-                             dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
+                             on_the_fly ? dev->step : dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
                              lg->dst.as<double>(), lg->m, sd ? lg->idx_s.as<int64_t>() : lg->nb_idx.as<int64_t>(), 1024, lg->stream,
                              lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr, sd ? lg->pt_s.as<double>() : nullptr);
 }
@@ -2084,10 +2077,7 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
         lg->nn_seeded = true;  // nb_idx (idx_s) now holds this step's neighbours
         return ICPX_OK;
     }
-    if (MODE == 0) {
-        hipLaunchKernelGGL(lg_step_kernel<D>, dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->cur.as<double>(), lg->n);
-        ICPX_HIP(hipGetLastError());
-    }
+    // (MODE 0: the queries are step * cur, computed by every workgroup on the fly; lg_sum1 writes the stepped cloud)
     // queries per thread (large_begin): 4, or fewer for clouds whose tiles would not fill the chip
     auto kern = lg->tile_qpt == 1 ? lg_tile_nn_kernel<D, MODE, 1> : (lg->tile_qpt == 2 ? lg_tile_nn_kernel<D, MODE, 2> : lg_tile_nn_kernel<D, MODE, 4>);
     const size_t lds = tile_lds_bytes(D, lg->split_len);
@@ -2213,9 +2203,10 @@ int lg_kd_service(LargeIcp* lg, int mode, bool* stalled) {
     hipLaunchKernelGGL(lg_kd_resume_kernel, dim3(1), dim3(64), 0, lg->stream, dev);
     ICPX_HIP(hipGetLastError());
     const bool sd = lg->sd && mode == 0;
-    ICPX_TRY(kd_launch_resolve(lg->dim, &dev->kd_count, lg->kd_list.as<uint32_t>(), mode, lg->src.as<double>(),
+    const bool on_the_fly = lg->dim == 3 && mode == 0 && lg->tile;
+    ICPX_TRY(kd_launch_resolve(lg->dim, &dev->kd_count, lg->kd_list.as<uint32_t>(), on_the_fly ? 4 : mode, lg->src.as<double>(),
                                sd ? lg->cur_s.as<double>() : lg->cur.as<double>(),
-                               dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
+                               on_the_fly ? dev->step : dev->st.transform, lg->kd_tree.as<uint32_t>(), lg->kd_tree.as<uint32_t>() + lg->m,
                                lg->dst.as<double>(), lg->m, sd ? lg->idx_s.as<int64_t>() : lg->nb_idx.as<int64_t>(), 1024, lg->stream,
                                lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr, sd ? lg->pt_s.as<double>() : nullptr));
     *stalled = true;
