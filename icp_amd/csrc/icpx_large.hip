@@ -1313,7 +1313,8 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
             bs.ext[d] = 0.0;
         }
     }
-    const double target_cells = std::max<double>(1.0, static_cast<double>(m) / 2.0);
+    const double per_cell = knobs().grid_density.load() > 0 ? knobs().grid_density.load() * 0.1 : 2.0;  // development knob ICPX_GRID_DENSITY
+    const double target_cells = std::max<double>(1.0, static_cast<double>(m) / per_cell);
     bs.h = 1.0;
     if (bs.nz > 0) {
         bs.h = std::pow(vol / target_cells, 1.0 / bs.nz);
