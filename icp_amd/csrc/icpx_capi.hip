@@ -479,14 +479,24 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     // Development override: ICPX_FUSED_SINGLE_MAX = largest n*m that stays fused
     double single_max = knobs().fused_single_max;
     if (single_max < 0.0) single_max = kFusedSingleMaxWork;
-    // A single scan-sized pair iterates faster with the brute-force filter (scan1, 22 iterations: 1.6 ms
-    // against 2.1 ms through the grid), so handles keep it; ICPX_PRUNE_HANDLES=1 sends them through the
-    // grid-pruned kernels of the batch path (tests do, to run the whole handle suite over those kernels)
+    // Single pairs keep the brute-force filter kernels (and the measured crossover to the multi-kernel path).  The
+    // grid-pruned kernels of the batch path are 1.5 - 2.7x faster per iteration on UNIFORM clouds of every size the fused
+    // kernel takes (round 3, ICPX_PRUNE_HANDLES=1: 2D trimmed 1000 points 48 -> 18 us, 3D 1024 68 -> 34, 3D 4096
+    // 107 -> 70 us) but 6x SLOWER on the reference's lidar scans (scan1, 22 iterations: 1.42 -> 8.6 ms): the points of a
+    // scan lie on curves, most cells of a uniform grid are empty and the occupied ones hold dozens of points, so the
+    // boxes overflow the candidate list and fall back to whole-wave scans.  Handles — the reference's use — take the
+    // robust path; ICPX_PRUNE_HANDLES=1 selects the pruned kernels (then for every size that fits; tests run both).
     const bool prune_handles = knobs().prune_handles != 0;
-    bool fused = h->prm.nn_mode != ICPX_NN_GRID && h->prm.nn_mode != ICPX_NN_BVH && fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles) &&
-                 static_cast<double>(n) * static_cast<double>(m) <= single_max &&
+    const bool fits = fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles);
+    bool fused = h->prm.nn_mode != ICPX_NN_GRID && h->prm.nn_mode != ICPX_NN_BVH && fits &&
+                 (h->geom.prune || static_cast<double>(n) * static_cast<double>(m) <= single_max) &&
                  h->method != ICPX_FEATURE_AWARE &&  // feature_aware and the opt-in corrected modes run on
                  h->prm.flags == 0;                  // the multi-kernel path only
+    // (nn = brute asks for the brute-force search: no pruned kernel)
+    if (fused && h->geom.prune && h->prm.nn_mode == ICPX_NN_BRUTE) {
+        fused = fused_fits(h->dim, h->method, n, m, &h->geom, true, false) &&
+                static_cast<double>(n) * static_cast<double>(m) <= single_max;
+    }
     // the tiled brute force of the large path is only chosen explicitly
     h->large = !fused;
     if (h->large && (n == 0 || m == 0)) {

@@ -34,7 +34,7 @@ struct Knobs {
     std::atomic<int> filter{1};          // ICPX_FILTER: 0 = plain f64 brute force (no f32 candidate filter)
     std::atomic<int> sched{-1};          // ICPX_SCHED: -1 auto, 0 never, 1 always (iteration-granular scheduler)
     std::atomic<int> sched_steps{0};     // ICPX_SCHED_STEPS: iterations per scheduler task, 0 = default
-    std::atomic<int> prune_handles{0};   // ICPX_PRUNE_HANDLES: 1 = handles run the grid-pruned kernels too
+    std::atomic<int> prune_handles{0};   // ICPX_PRUNE_HANDLES: 1 = handles (single pairs) run the grid-pruned kernels of the batch path
     std::atomic<int> no_group_sums{0};   // ICPX_NO_GROUP_SUMS: 1 = multi-kernel path always sums in 4096-point blocks
     std::atomic<int> geom_qpt{0}, geom_threads{0};      // ICPX_GEOM="qpt,threads"
     std::atomic<double> fused_single_max{-1.0};         // ICPX_FUSED_SINGLE_MAX: largest n*m of a handle that stays fused; < 0 = default

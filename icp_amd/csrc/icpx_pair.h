@@ -402,6 +402,8 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
 //                   to pad_to; null (only when hc is null): not staged
 // Called from pair_perm_kernel (separate launch) and from the pair kernels' setup visit (icpx_pair_pruned.h), where
 // ts is the kernel's own target area.  Workgroup-wide (barriers); ends with a barrier.
+constexpr double kGridSigmas = 3.0;  // (a uniform cloud's box is mean +- 1.73 sigma: unchanged)
+
 template <int D>
 ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int cnt, uint16_t* __restrict__ out,
                                       uint16_t* __restrict__ table, uint16_t* table_lds, float* __restrict__ hc, double* red,
@@ -414,6 +416,15 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
         hi[d] = -__builtin_inf();
     }
     bool bad = false;
+    // (first and second moments beside the bounding box: the grid covers mean +- kGridSigmas standard deviations when
+    // that is inside the box — a scan with a few far returns would otherwise spend its cells on empty space; the
+    // points beyond it fall into the border cells, cell_of clamps.  Any box gives the same search results.)
+    double s1[D], s2[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        s1[d] = 0.0;
+        s2[d] = 0.0;
+    }
     for (int i = tid; i < cnt; i += T)
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -421,6 +432,8 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
             if (__builtin_fabs(v) < 1e150) {
                 lo[d] = __builtin_fmin(lo[d], v);
                 hi[d] = __builtin_fmax(hi[d], v);
+                s1[d] += v;
+                s2[d] += v * v;
             } else {
                 bad = true;
             }
@@ -431,6 +444,8 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
         for (int o = 32; o >= 1; o >>= 1) {
             lo[d] = __builtin_fmin(lo[d], __shfl_xor(lo[d], o));
             hi[d] = __builtin_fmax(hi[d], __shfl_xor(hi[d], o));
+            s1[d] += __shfl_xor(s1[d], o);
+            s2[d] += __shfl_xor(s2[d], o);
         }
         if (lane == 0) {
             red[wave * 8 + d] = lo[d];
@@ -454,6 +469,37 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
         if (!(l <= h)) {  // no usable coordinate on this axis
             l = 0.0;
             h = 0.0;
+        }
+        lo[d] = l;
+        hi[d] = h;
+    }
+    // the moments through the same scratch words (everyone has read the box)
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            red[wave * 8 + d] = s1[d];
+            red[wave * 8 + 4 + d] = s2[d];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        double l = lo[d], h = hi[d];
+        if (!any_bad && cnt > 1) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < W; w++) {
+                a += red[w * 8 + d];
+                b += red[w * 8 + 4 + d];
+            }
+            const double mean = a / static_cast<double>(cnt);
+            const double var = b / static_cast<double>(cnt) - mean * mean;
+            const double sd = var > 0.0 ? __builtin_sqrt(var) : 0.0;
+            const double l2 = __builtin_fmax(l, mean - kGridSigmas * sd), h2 = __builtin_fmin(h, mean + kGridSigmas * sd);
+            if (l2 < h2 && (h2 - l2) < 1e300) {
+                l = l2;
+                h = h2;
+            }
         }
         lo[d] = l;
         scale[d] = h > l ? static_cast<double>(G) / (h - l) : 0.0;
