@@ -64,6 +64,7 @@ bool set_knob(Knobs& k, const char* name, const char* value) {
     else if (n == "ICPX_GRID_COOP") k.grid_coop = value ? (value[0] == '2' ? 2 : (value[0] != '0')) : 1;
     else if (n == "ICPX_POLL_DONE") k.poll_done = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_GRID_SEED") k.grid_seed = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_DEFER_SPARSE") k.defer_sparse = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_GRID_DENSITY") k.grid_density = (value && iv >= 1 && iv <= 1000) ? iv : 0;
     else if (n == "ICPX_GRID_SD") k.grid_sd = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_TILE_MIN") k.tile_min = (value && iv >= 64 && iv <= 3072) ? (iv & ~3) : 0;
@@ -90,7 +91,7 @@ Knobs& knobs() {
     static Knobs k;
     static const bool from_env = [] {
         for (const char* n : {"ICPX_PRUNE", "ICPX_FILTER", "ICPX_SCHED", "ICPX_SCHED_STEPS", "ICPX_PRUNE_HANDLES",
-                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
+                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_DEFER_SPARSE", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
             if (const char* v = std::getenv(n)) set_knob(k, n, v);
         return true;
     }();
@@ -248,20 +249,48 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     if (g.prune && !prune) return fail(ICPX_ERR_INVALID, "pruned launch without its permutation buffers");
     const bool kd_rule = pb.dim == 3 || pb.method == ICPX_VANILLA;
     if (kd_rule && (!pb.kdnode || !pb.kdpos || !pb.kd_paused)) return fail(ICPX_ERR_INVALID, "launch without the kd rule's buffers");
-    if (pb.dim == 2) return prune ? launch_pairs_d2_prune(pb, n_pairs, pl, stream) : launch_pairs_d2_plain(pb, n_pairs, pl, stream);
+    // pruned kernels hand the pairs whose grid is a poor index (lidar scans: points on curves) to a brute-force kernel
+    // launched behind them (PairGrid::bad bit 1, icpx_pair_pruned.h); development knob ICPX_DEFER_SPARSE=0
+    const bool defer = prune && pb.kd_paused != nullptr && knobs().defer_sparse != 0;
+    pb.defer_sparse = defer ? 1 : 0;
+    if (pb.dim == 2) {
+        if (!defer) return prune ? launch_pairs_d2_prune(pb, n_pairs, pl, stream) : launch_pairs_d2_plain(pb, n_pairs, pl, stream);
+        PairGeom g2;
+        if (!fused_fits(2, pb.method, static_cast<int64_t>(g.qpt) * g.threads, g.m, &g2, g.scap > 0, false)) {
+            pb.defer_sparse = 0;  // (no brute-force geometry for these sizes: every pair stays with the pruned kernel)
+            return launch_pairs_d2_prune(pb, n_pairs, pl, stream);
+        }
+        ICPX_HIP(hipMemsetAsync(pb.kd_paused, 0, sizeof(int32_t), stream));
+        ICPX_TRY(launch_pairs_d2_prune(pb, n_pairs, pl, stream));
+        PairBatch tb = pb;
+        tb.kd_takeover = 1;
+        tb.defer_sparse = 0;
+        tb.sched_state = nullptr;
+        tb.lds_target_cap = g2.tcap;
+        tb.lds_sort_cap = g2.scap;
+        tb.use_filter = g2.filter ? 1 : 0;
+        PairLaunch tl;
+        tl.qpt = g2.qpt;
+        tl.threads = g2.threads;
+        tl.lds = g2.lds;
+        tl.cus = di->cus;
+        return launch_pairs_d2_plain(tb, n_pairs, tl, stream);
+    }
     // 3D: the kernels only detect the kd rule's ties; a pair that meets one stops there and the KD kernel enqueued
     // behind takes it over (a launch that finds nothing to do when no pair stopped)
     ICPX_HIP(hipMemsetAsync(pb.kd_paused, 0, sizeof(int32_t), stream));
     ICPX_TRY(prune ? launch_pairs_d3_prune(pb, n_pairs, pl, stream) : launch_pairs_d3_plain(pb, n_pairs, pl, stream));
     PairBatch tb = pb;
     tb.kd_takeover = 1;
+    tb.defer_sparse = 0;
     tb.sched_state = nullptr;
     tb.use_filter = 0;
     tb.lds_sort_cap = 0;
     tb.do_setup = 0;
     PairLaunch tl;
-    tl.qpt = 8;
-    tl.threads = 512;
+    const bool small = static_cast<int64_t>(g.qpt) * g.threads <= 1024;
+    tl.qpt = small ? 4 : 8;
+    tl.threads = small ? 256 : 512;
     tl.lds = pair_lds_bytes_kd(3, g.tcap, 0, g.m);
     tl.cus = di->cus;
     return launch_pairs_d3_plain(tb, n_pairs, tl, stream);

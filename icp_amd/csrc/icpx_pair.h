@@ -92,6 +92,8 @@ struct PairBatch {
     int32_t* kd_paused;        // one word: pairs that a kernel without the rule's resolution paused at a tie
                                // (PairState::kd_flags bit 1); the KD kernel launched behind it takes them over
     int32_t kd_takeover;       // this launch is that KD kernel: only paused pairs run, from where they stopped
+                               // (and pairs deferred by the pruned kernel, bit 2 of kd_flags: from the beginning)
+    int32_t defer_sparse;      // pruned kernels: hand pairs whose grid is a poor index (PairGrid::bad bit 1) to the kernel launched behind
 };
 
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
@@ -403,6 +405,12 @@ ICPX_DEV void radix_select(const uint64_t (&key)[QPT], const bool (&valid)[QPT],
 // Called from pair_perm_kernel (separate launch) and from the pair kernels' setup visit (icpx_pair_pruned.h), where
 // ts is the kernel's own target area.  Workgroup-wide (barriers); ends with a barrier.
 constexpr double kGridSigmas = 3.0;  // (a uniform cloud's box is mean +- 1.73 sigma: unchanged)
+// The grid is a poor index of a cloud when sum(cell count^2) / points — the points a query that falls among the targets
+// finds in its own cell — passes max(kSparseFloor, points * kSparseNum / kSparseDen): a uniform cloud has 2, the
+// reference's lidar scans 32..61 at 660..960 points, a sphere's surface 4, a circle 10 (measured at 1024 points: the
+// pruned kernels win 3x at 10 and lose 2.4x at 23; the brute-force kernels' work grows with the point count)
+constexpr int kSparseFloor = 8, kSparseNum = 1, kSparseDen = 64;
+constexpr int kSparseMinPoints = 128;
 
 template <int D>
 ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int cnt, uint16_t* __restrict__ out,
@@ -522,17 +530,22 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
         for (int d = D - 1; d >= 0; d--) c = c * G + cell_of(pts[static_cast<int64_t>(i) * D + d], lo[d], scale[d], G);
         return c;
     };
-    for (int c = tid; c <= ncell; c += T) hist[c] = 0;
+    for (int c = tid; c <= ncell + 1; c += T) hist[c] = 0;  // (hist[ncell + 1]: sum of squared cell counts)
     __syncthreads();  // (also: every thread has read `red`)
     for (int i = tid; i < cnt; i += T) atomicAdd(&hist[cell_id(i)], 1);
     __syncthreads();
     // exclusive scan of the cell counts: per-thread chunk, wave scan, wave totals
     const int chunk = (ncell + T - 1) / T;
-    int local = 0;
+    int local = 0, occ = 0;
     for (int u = 0; u < chunk; u++) {
         const int c = tid * chunk + u;
-        if (c < ncell) local += hist[c];
+        if (c < ncell) {
+            local += hist[c];
+            occ += hist[c] * hist[c];
+        }
     }
+    occ = wave_sum_int(occ);
+    if (lane == 0 && occ) atomicAdd(&hist[ncell + 1], occ);
     int incl = local;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -558,6 +571,14 @@ ICPX_DEV PairGrid prepare_target_grid(const double* __restrict__ pts, const int 
         if (table_lds) table_lds[ncell] = static_cast<uint16_t>(cnt);
     }
     __syncthreads();
+    // a cloud with many points in few cells — a lidar scan: dense returns near the sensor, points on curves, most
+    // cells empty — is searched faster by the brute-force filter kernels (a batch of the reference's scan pairs:
+    // 5.5x): bit 1 of `bad` tells the pruned kernel to hand the pair over when it can (icpx_pair_pruned.h)
+    {
+        const long long per_query = static_cast<long long>(cnt) * kSparseNum / kSparseDen;
+        const long long limit = per_query > kSparseFloor ? per_query : kSparseFloor;
+        if (cnt >= kSparseMinPoints && static_cast<long long>(hist[ncell + 1]) > limit * cnt) g.bad |= 2;
+    }
     // the order inside a cell is whatever the atomics give: any order is a valid permutation.  The cloud goes
     // into LDS in that order at once
     for (int i = tid; i < cnt; i += T) {
@@ -808,7 +829,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     // kd rule: is the pair's tree built (bit 0)?  A take-over visit (bit 1 was set by the kernel that stopped at a
     // tie) resumes INSIDE the loop: that kernel has already evaluated should_terminate and copied state -> last_state
     bool kd_ready = (reinterpret_cast<int*>(L.bc + 41)[0] & 1) != 0;
-    bool kd_resume = KD && pb.kd_takeover != 0;
+    bool kd_resume = KD && pb.kd_takeover != 0 && !do_setup;
     // KD kernels: flagged queries of one search are resolved here, by the whole workgroup (barriers)
     auto kd_fix = [&](const double (&q)[QPT][D], const double (&best)[QPT], int (&pair_)[QPT], const int (&tie)[QPT],
                       const bool (&valid_)[QPT]) {
@@ -1196,18 +1217,18 @@ ICPX_DEV int pair_visit(const PairBatch& pb, const int p, const int do_setup, co
 template <int D, int METHOD, int QPT, int TMAX, bool PRUNE, bool KD>
 __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX, PRUNE)) pair_kernel(const PairBatch pb) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    if constexpr (KD) {
-        if (pb.kd_takeover) {
-            // the KD kernel behind a launch that only detects ties: workgroup b looks after pair b, if that launch
-            // stopped it at a tie; from where it stopped (icpx_pair.h, pair_body)
-            if (__hip_atomic_load(pb.kd_paused, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-            const bool paused = (pb.states[blockIdx.x].kd_flags & 2) != 0;
-            __syncthreads();
-            if (!paused) return;
-            if (threadIdx.x == 0) pb.states[blockIdx.x].kd_flags &= ~static_cast<uint64_t>(2);
-            (void)pair_visit<D, METHOD, QPT, PRUNE, KD>(pb, blockIdx.x, 0, pb.max_steps, lds_raw);
-            return;
-        }
+    if (pb.kd_takeover) {
+        // the kernel behind a launch that only detects the kd rule's ties (KD kernels: workgroup b looks after pair b if
+        // that launch stopped it at a tie, from where it stopped) and / or hands over pairs its grid does not suit (bit 2
+        // of kd_flags: from the beginning, icpx_pair_pruned.h)
+        if (__hip_atomic_load(pb.kd_paused, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        const int flags = static_cast<int>(pb.states[blockIdx.x].kd_flags);
+        __syncthreads();
+        const bool fresh = (flags & 4) != 0, paused = KD && (flags & 2) != 0;
+        if (!fresh && !paused) return;
+        if (threadIdx.x == 0) pb.states[blockIdx.x].kd_flags &= ~static_cast<uint64_t>(6);
+        (void)pair_visit<D, METHOD, QPT, PRUNE, KD>(pb, blockIdx.x, fresh ? 1 : 0, pb.max_steps, lds_raw);
+        return;
     }
     // Two ways of handing out pairs, ONE call site of the pair's code (it is large):
     //   plain      workgroup b runs pair b from begin to end;

@@ -96,13 +96,21 @@ int ICPX_INST_NAME(ICPX_INST_DIM)(const PairBatch& pb, int64_t n_pairs, const Pa
     constexpr int D = ICPX_INST_DIM;
     constexpr bool PRUNE = ICPX_INST_PRUNE != 0;
     if (pb.kd_takeover) {
-        // the 3D kernel that resolves the kd rule's ties (one geometry: any n <= 4096), behind a launch that only detects them
+        // the kernel behind a launch that detects the kd rule's ties (3D: two geometries, n <= 1024 and n <= 4096) and / or hands
+        // over the pairs its grid does not suit (2D trimmed: the brute-force filter kernel of the run's geometry)
         if constexpr (D == 3 && !PRUNE) {
-            if (g.qpt != 8 || g.threads != 512) return fail(ICPX_ERR_INVALID, "the kd take-over kernel runs 8 queries per lane x 512 threads");
+            if (g.qpt == 4 && g.threads == 256) {  // (sources of up to 1024 points: the batch kernels' own geometry)
+                if (pb.method == ICPX_VANILLA) return launch_one<3, ICPX_VANILLA, 4, 256, false, true>(pb, n_pairs, g, stream);
+                return launch_one<3, ICPX_TRIMMED, 4, 256, false, true>(pb, n_pairs, g, stream);
+            }
+            if (g.qpt != 8 || g.threads != 512) return fail(ICPX_ERR_INVALID, "the kd take-over kernel runs 4 x 256 or 8 x 512 (queries per lane x threads)");
             if (pb.method == ICPX_VANILLA) return launch_one<3, ICPX_VANILLA, 8, 512, false, true>(pb, n_pairs, g, stream);
             return launch_one<3, ICPX_TRIMMED, 8, 512, false, true>(pb, n_pairs, g, stream);
+        } else if constexpr (D == 2 && !PRUNE) {
+            if (pb.method != ICPX_TRIMMED) return fail(ICPX_ERR_INVALID, "no take-over kernel for this method");
+            return launch_dm<2, ICPX_TRIMMED, false>(pb, n_pairs, g, stream);
         } else {
-            return fail(ICPX_ERR_INVALID, "no kd take-over kernel in this object");
+            return fail(ICPX_ERR_INVALID, "no take-over kernel in this object");
         }
     }
     if (pb.method == ICPX_VANILLA) {

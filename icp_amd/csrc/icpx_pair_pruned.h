@@ -67,8 +67,27 @@ ICPX_DEV int pair_body_pruned(const PairBatch& pb, const int p_in, const int do_
             P.g.lo[d] = uniform_double(P.g.lo[d]);
             P.g.scale[d] = uniform_double(P.g.scale[d]);
         }
+        if (do_setup && pb.defer_sparse && (P.g.bad & 2) != 0) {
+            // this cloud's grid is a poor index: the brute-force kernel launched behind runs the pair, from the beginning
+            if (tid == 0) {
+                st->kd_flags = 4;
+                atomicAdd(pb.kd_paused, 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            return 1;
+        }
     } else {
         P.g = pb.grids[p];
+        if (do_setup && pb.defer_sparse && (P.g.bad & 2) != 0) {  // (grids from the separate pre-pass launch)
+            if (tid == 0) {
+                st->kd_flags = 4;
+                atomicAdd(pb.kd_paused, 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            return 1;
+        }
         int ncell = P.g.G;
         for (int d = 1; d < D; d++) ncell *= P.g.G;
         for (int c = tid; c <= ncell; c += T) table[c] = pb.cstart[static_cast<int64_t>(p) * kGridTable + c];

@@ -30,7 +30,8 @@ struct PairGrid {        // per target cloud, written by the pre-pass
     double lo[3];
     double scale[3];     // cells per unit length
     int G;               // cells per axis
-    int bad;             // a coordinate is not finite or >= 1e150: no pruning
+    int bad;             // bit 0: a coordinate is not finite or >= 1e150: no pruning; bit 1: occupied cells hold many
+                         // points each (prepare_target_grid): the brute-force kernels suit this cloud better
 };
 
 struct GridView {
@@ -239,7 +240,7 @@ ICPX_DEV bool seed_certified(double d2_seed, double hc) {
 template <int D, bool TIES = false>
 ICPX_DEV void nn_grid_slot(const double (&q)[D], const bool v, const bool seeded, const LdsView<D>& L,
                            const GridView& P, double& best, int& bslot, int* tie = nullptr) {
-    bool fin = P.g.bad == 0;
+    bool fin = (P.g.bad & 1) == 0;
 #pragma unroll
     for (int d = 0; d < D; d++) fin = fin && (__builtin_fabs(q[d]) < 1e150);
     if (__any(v && !fin)) {
@@ -712,7 +713,7 @@ ICPX_DEV bool box_inside(const int (&a0)[D], const int (&a1)[D], const int (&b0)
 template <int D, bool TIES = false>
 ICPX_DEV void nn_coop_slot(const double (&q)[D], const bool v, const bool seeded, const LdsView<D>& L,
                            const GridView& P, const CoopStage<D>& S, double& best, int& bslot, int* tie = nullptr) {
-    bool fin = P.g.bad == 0;
+    bool fin = (P.g.bad & 1) == 0;
 #pragma unroll
     for (int d = 0; d < D; d++) fin = fin && (__builtin_fabs(q[d]) < 1e150);
     if (__any(v && !fin)) {  // non-finite or huge coordinates in this wave: the per-lane path knows them

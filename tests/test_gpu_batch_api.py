@@ -194,3 +194,51 @@ def test_time_limit_on_the_multi_kernel_path_is_not_halved(icp):
     assert r.iteration_count < 100000
     assert wall >= limit, (wall, r.iteration_count)
     assert wall < limit + 1.0, (wall, r.iteration_count)
+
+
+@pytest.mark.parametrize("dim,method", [(2, "trimmed"), (2, "vanilla"), (3, "trimmed"), (3, "vanilla")])
+def test_pairs_whose_grid_is_a_poor_index_are_handed_over(icp, scans, knob, dim, method):
+    """Clouds with most points in few cells of the per-pair grid (the reference's lidar scans, ex_data/scan*;
+    in 3D points on a curve, or half of them in a small clump): the grid-pruned kernels hand such pairs to the
+    brute-force kernel launched behind them.  A batch that mixes them with uniform clouds returns, pair by
+    pair, bit for bit what the pruned kernels alone (ICPX_DEFER_SPARSE=0), the brute-force kernels alone
+    (ICPX_PRUNE=0) and the pairs' own handles return."""
+    from icp_amd import synth
+    rng = np.random.default_rng(17)
+    crit_kw = dict(max_iterations=30, transform_tol=(0.1 * np.pi / 180, 0.01))
+    crit = icp.make_criteria(**crit_kw)
+    clouds = []
+    for k in range(12):
+        if k % 3 == 2:
+            s, t, _, _ = synth.config5_pairs([300 + k], dim, 900)
+            clouds.append((s[:700 + 10 * k].copy(), t.copy()))
+        elif dim == 2:
+            a, b = scans[1 + k % 3]
+            clouds.append((a, b + 0.01 * k))
+        else:
+            if k % 2:
+                x = rng.uniform(size=1000)
+                t = 5.0 * np.c_[x, np.sin(6 * x), np.cos(5 * x)]
+            else:
+                t = np.r_[rng.uniform(0, 5, (500, 3)), rng.uniform(2, 3, (500, 3))]
+                rng.shuffle(t)
+            a = np.radians(2.0 + k)
+            R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            clouds.append(((t[:800] @ R.T + [0.1, -0.05, 0.02 * k]).copy(), t))
+    so = np.cumsum([0] + [len(a) for a, _ in clouds]).astype(np.int64)
+    to = np.cumsum([0] + [len(b) for _, b in clouds]).astype(np.int64)
+    S = np.ascontiguousarray(np.concatenate([a for a, _ in clouds]))
+    T = np.ascontiguousarray(np.concatenate([b for _, b in clouds]))
+    got = icp.converge_batch(dim, method, S, so, T, to, crit)
+    knob.set("ICPX_DEFER_SPARSE", 0)
+    pruned = icp.converge_batch(dim, method, S, so, T, to, crit)
+    knob.reset("ICPX_DEFER_SPARSE")
+    knob.set("ICPX_PRUNE", 0)
+    brute = icp.converge_batch(dim, method, S, so, T, to, crit)
+    knob.reset("ICPX_PRUNE")
+    for other in (pruned, brute):
+        for a, b in zip(got, other):
+            assert np.array_equal(a, b)
+    cost, its, Ts = got
+    for p, r in enumerate(handle_results(icp, dim, method, None, crit_kw, clouds)):
+        assert its[p] == r.iteration_count and cost[p] == r.cost and np.array_equal(Ts[p], r.transform), p
