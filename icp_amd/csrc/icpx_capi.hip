@@ -65,6 +65,7 @@ bool set_knob(Knobs& k, const char* name, const char* value) {
     else if (n == "ICPX_POLL_DONE") k.poll_done = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_GRID_SEED") k.grid_seed = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_DEFER_SPARSE") k.defer_sparse = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_CHUNK_SKIP") k.chunk_skip = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_GRID_DENSITY") k.grid_density = (value && iv >= 1 && iv <= 1000) ? iv : 0;
     else if (n == "ICPX_GRID_SD") k.grid_sd = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_TILE_MIN") k.tile_min = (value && iv >= 64 && iv <= 3072) ? (iv & ~3) : 0;
@@ -91,7 +92,7 @@ Knobs& knobs() {
     static Knobs k;
     static const bool from_env = [] {
         for (const char* n : {"ICPX_PRUNE", "ICPX_FILTER", "ICPX_SCHED", "ICPX_SCHED_STEPS", "ICPX_PRUNE_HANDLES",
-                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_DEFER_SPARSE", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
+                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_DEFER_SPARSE", "ICPX_CHUNK_SKIP", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
             if (const char* v = std::getenv(n)) set_knob(k, n, v);
         return true;
     }();
@@ -170,6 +171,7 @@ struct PairGeom {
     bool kd;      // KD kernel (2D vanilla): the kd rule's ties are resolved in the kernel (icpx_kd.h)
     bool filter;  // f32 target copy reserved in LDS (nn_filtered)
     bool prune;   // grid-pruned search (icpx_prune.h): targets ordered by cell, cell table in LDS
+    bool chunk;   // trimmed ICP2, brute-force kernels: chunk-skipping exact search (nn_lds_chunked) instead of the filter
     size_t lds;
 };
 
@@ -212,6 +214,15 @@ bool fused_fits(int dim, int method, int64_t n, int64_t m, PairGeom* g, bool wan
         }
     }
     r.lds = pair_lds_bytes(dim, r.tcap, r.scap, r.filter, r.prune, r.threads);
+    // trimmed ICP2 without the grid: the exact scan skips the chunks of 32 consecutive targets whose box no query of
+    // the wave can reach (icpx_filter.h) — the reference's lidar scans come in scan order.  Development knob: ICPX_CHUNK_SKIP=0
+    r.chunk = false;
+    if (dim == 2 && method == ICPX_TRIMMED && !r.prune && knobs().chunk_skip != 0 && m >= 2 * kChunk &&
+        pair_lds_bytes_chunk(2, r.tcap, r.scap) <= kMaxLds) {
+        r.chunk = true;
+        r.filter = false;
+        r.lds = pair_lds_bytes_chunk(2, r.tcap, r.scap);
+    }
     r.m = m;
     r.kd = dim == 2 && method == ICPX_VANILLA;
     // the kd rule (icpx_kd.h): a pair's tree is built in the kernel's LDS on its first tie — by the 2D vanilla kernels
@@ -232,6 +243,7 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     pb.lds_target_cap = g.tcap;
     pb.lds_sort_cap = g.scap;
     pb.use_filter = g.filter ? 1 : 0;
+    pb.chunk_skip = g.chunk ? 1 : 0;
     pb.coop = knobs().coop != 0 ? 1 : 0;
 #ifdef ICPX_PROBE
     if (const char* pe = std::getenv("ICPX_PROBE_MASK")) pb.coop |= std::atoi(pe);
@@ -269,6 +281,7 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
         tb.lds_target_cap = g2.tcap;
         tb.lds_sort_cap = g2.scap;
         tb.use_filter = g2.filter ? 1 : 0;
+        tb.chunk_skip = g2.chunk ? 1 : 0;
         PairLaunch tl;
         tl.qpt = g2.qpt;
         tl.threads = g2.threads;
@@ -285,6 +298,7 @@ int launch_pairs(PairBatch& pb, int64_t n_pairs, const PairGeom& g, hipStream_t 
     tb.defer_sparse = 0;
     tb.sched_state = nullptr;
     tb.use_filter = 0;
+    tb.chunk_skip = 0;
     tb.lds_sort_cap = 0;
     tb.do_setup = 0;
     PairLaunch tl;

@@ -97,6 +97,113 @@ ICPX_DEV void nn_lds(const double (&q)[QPT][D], const LdsView<D>& L, int m4, dou
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chunk-skipping exact search (trimmed ICP2 in the brute-force kernels).  The targets stay in cloud order; every
+// kChunk consecutive ones carry their bounding box.  One query slot at a time, the wave walks the chunks in ascending
+// order and evaluates a chunk — with nn_lds's block code, for all lanes — only if SOME lane's query can have a target
+// there that is not farther than its bound: the smaller of its running minimum and the exact distance to its seed
+// (the previous neighbour).  Exactness: for a target t of the chunk and every axis |t - q| >= g = max(lo - q,
+// q - hi, 0) in real numbers; rounded differences, their rounded squares and the rounded sums of non-negative terms
+// are monotone, so the computed d2 = ((dx dx) + dy dy) + dz dz is >= lb = ((gx gx) + gy gy) + gz gz computed the
+// same way.  A chunk is skipped only if lb > bound, strictly: every target with d2 <= bound — the seed itself, equal
+// distances with lower indices — is evaluated, in ascending order with strict <, which is nn_lds's rule; the seed only
+// bounds, it is never taken as the answer without having been scanned.  NaN bounds or coordinates never skip.
+// What it buys depends on coherence: the points of a lidar scan come in scan order, so the 64 queries of a wave-slot
+// are neighbours and so are the 32 targets of a chunk — ex_data/scan1: 4 of 30 chunks evaluated per wave-slot.  Clouds
+// in random order evaluate every chunk (the cost of nn_lds plus the tests).
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunk = 32;
+
+// boxes of the staged cloud: cb[(c * 2 + 0) * D + d] = min, cb[(c * 2 + 1) * D + d] = max over targets [c kChunk,
+// (c + 1) kChunk) below m (NaN coordinates are ignored; an empty or all-NaN chunk gets +inf / -inf and is never needed).
+// Workgroup-wide; ends with a barrier.
+template <int D>
+ICPX_DEV void chunk_boxes(const LdsView<D>& L, const int m, double* __restrict__ cb) {
+    const int nch = (m + kChunk - 1) / kChunk;
+    for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+        double lo[D], hi[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            lo[d] = __builtin_inf();
+            hi[d] = -__builtin_inf();
+        }
+        const int j1 = min((c + 1) * kChunk, m);
+        for (int j = c * kChunk; j < j1; j++)
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const double v = L.t[d][j];
+                lo[d] = __builtin_fmin(lo[d], v);
+                hi[d] = __builtin_fmax(hi[d], v);
+            }
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            cb[(c * 2 + 0) * D + d] = lo[d];
+            cb[(c * 2 + 1) * D + d] = hi[d];
+        }
+    }
+    __syncthreads();
+}
+
+// bound[k]: exact d2 of slot k's query to some target of the cloud (+inf: none).  Out: what nn_lds returns.
+template <int D, int QPT>
+ICPX_DEV void nn_lds_chunked(const double (&q)[QPT][D], const bool (&valid)[QPT], const LdsView<D>& L, const int m,
+                             const int m4, const double* __restrict__ cb, const double (&bound)[QPT],
+                             double (&best)[QPT], int (&bidx)[QPT]) {
+    const int nch = (m + kChunk - 1) / kChunk;
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        double bst = __builtin_inf();
+        int bblk = 0;
+        const double bnd = bound[k];
+        for (int c = 0; c < nch; c++) {
+            double lb = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const double lo = cb[(c * 2 + 0) * D + d], hi = cb[(c * 2 + 1) * D + d];
+                const double g = __builtin_fmax(__builtin_fmax(lo - q[k][d], q[k][d] - hi), 0.0);
+                lb = d == 0 ? g * g : lb + g * g;
+            }
+            const double lim = __builtin_fmin(bst, bnd);  // (a NaN bound leaves the running minimum)
+            if (!__any(valid[k] && !(lb > lim))) continue;
+            const int j1 = min((c + 1) * kChunk, m4);
+            for (int jb = c * kChunk; jb < j1; jb += 4) {
+                double dist[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    double df = L.t[0][jb + u] - q[k][0];
+                    double acc = df * df;
+#pragma unroll
+                    for (int d = 1; d < D; d++) {
+                        df = L.t[d][jb + u] - q[k][d];
+                        acc = acc + df * df;
+                    }
+                    dist[u] = acc;
+                }
+                const double mm = __builtin_fmin(__builtin_fmin(dist[0], dist[1]), __builtin_fmin(dist[2], dist[3]));
+                const bool lt = mm < bst;
+                bst = __builtin_fmin(bst, mm);
+                bblk = lt ? jb : bblk;
+            }
+        }
+        int idx = 0;
+        if (bst < __builtin_inf()) {
+#pragma unroll
+            for (int u = 3; u >= 0; u--) {
+                double df = L.t[0][bblk + u] - q[k][0];
+                double acc = df * df;
+#pragma unroll
+                for (int d = 1; d < D; d++) {
+                    df = L.t[d][bblk + u] - q[k][d];
+                    acc = acc + df * df;
+                }
+                idx = acc == bst ? bblk + u : idx;
+            }
+        }
+        best[k] = bst;
+        bidx[k] = idx;
+    }
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // development statistics (build with -DICPX_STATS; read with icpx_debug_stats):

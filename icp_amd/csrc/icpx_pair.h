@@ -94,6 +94,8 @@ struct PairBatch {
     int32_t kd_takeover;       // this launch is that KD kernel: only paused pairs run, from where they stopped
                                // (and pairs deferred by the pruned kernel, bit 2 of kd_flags: from the beginning)
     int32_t defer_sparse;      // pruned kernels: hand pairs whose grid is a poor index (PairGrid::bad bit 1) to the kernel launched behind
+    int32_t chunk_skip;        // trimmed ICP2, brute-force kernels: chunk-skipping exact search (nn_lds_chunked, icpx_filter.h);
+                               // the launch reserved pair_lds_bytes_chunk (the boxes take the f32 copy's place)
 };
 
 inline __host__ __device__ size_t pair_lds_filter_offset(int dim, int tcap, int scap) {
@@ -132,6 +134,10 @@ inline size_t pair_lds_bytes(int dim, int tcap, int scap, bool filter, bool prun
         return pair_lds_filter_offset(dim, tcap, scap) + sizeof(uint16_t) * kGridTable +
                static_cast<size_t>(threads / 64) * coop_wave_bytes(dim);
     return pair_lds_filter_offset(dim, tcap, scap) + (filter ? sizeof(float) * static_cast<size_t>(dim) * tcap : 0);
+}
+// chunk-skipping search: the chunks' boxes behind the sort area
+inline size_t pair_lds_bytes_chunk(int dim, int tcap, int scap) {
+    return pair_lds_filter_offset(dim, tcap, scap) + sizeof(double) * 2 * dim * static_cast<size_t>((tcap + kChunk - 1) / kChunk);
 }
 // KD kernels: at least the tree build's scratch behind the group sums and the broadcast area
 inline size_t pair_lds_bytes_kd(int dim, int tcap, int scap, int64_t m) {
@@ -772,7 +778,9 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     const double* __restrict__ src = pb.src + s0 * D;
     const double* __restrict__ dst = pb.dst + d0 * D;
     PairState* st = pb.states + p;
-    const bool filter = !KD && pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
+    constexpr bool kChunkable = D == 2 && METHOD == ICPX_TRIMMED && !KD;
+    const bool chunked = kChunkable && pb.chunk_skip != 0;
+    const bool filter = !KD && !chunked && pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
     LdsView<D> L = carve<D>(lds_raw, pb.lds_target_cap, pb.lds_sort_cap, filter);
     L.cloud = dst;
     const bool empty = (n == 0 || m == 0);
@@ -780,6 +788,11 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     // ---- stage the target cloud into LDS as SoA (+ f32 copy about the bounding-box centre) ----
     const int m4 = (m + 3) & ~3;
     const FilterFrame F = stage_targets<D>(dst, m, m4, T, L, filter);
+    double* const cbox = reinterpret_cast<double*>(reinterpret_cast<char*>(lds_raw) +
+                                                   pair_lds_filter_offset(D, pb.lds_target_cap, pb.lds_sort_cap));
+    if constexpr (kChunkable) {
+        if (chunked) chunk_boxes<D>(L, m, cbox);
+    }
 
     // ---- per-thread point slots ----
     double a[QPT][D];    // 2D: source points; 3D: running cloud c
@@ -858,7 +871,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     // seeds for the filtered search: the previous nearest neighbours.  Trimmed ICP2 has them from
     // setup on; ICP3 after its first iterate; a resumed launch reloads them.
     bool have_seed = false;
-    if (filter && !do_setup && pb.seeds && !empty && (D == 2 || st->iteration_count > 0)) {
+    if ((filter || chunked) && !do_setup && pb.seeds && !empty && (D == 2 || st->iteration_count > 0)) {
 #pragma unroll
         for (int k = 0; k < QPT; k++) pair[k] = valid[k] ? pb.seeds[s0 + tid + k * T] : 0;
         have_seed = true;
@@ -893,10 +906,21 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 nn_lds<D, QPT, true>(q, L, m4, best, pair, tie);
                 kd_fix(q, best, pair, tie, valid);
             } else {
-                if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
+                bool searched = false;
+                if constexpr (kChunkable) {
+                    if (chunked) {
+                        double bound[QPT];
+#pragma unroll
+                        for (int k = 0; k < QPT; k++) bound[k] = __builtin_inf();
+                        nn_lds_chunked<D, QPT>(q, valid, L, m, m4, cbox, bound, best, pair);
+                        searched = true;
+                    }
+                }
+                if (searched) {
+                } else if (filter) nn_twomin<D, QPT>(q, L, m4, F, best, pair);
                 else nn_lds<D, QPT>(q, L, m4, best, pair);
             }
-            have_seed = filter;
+            have_seed = filter || chunked;
 #pragma unroll
             for (int k = 0; k < QPT; k++) {
                 if (METHOD == ICPX_VANILLA) cost[k] = __builtin_sqrt(__builtin_sqrt(best[k]));  // vanilla.cpp:84 on kdtree.h:126
@@ -978,12 +1002,27 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                 for (int k = 0; k < QPT; k++) xf_apply<D>(xr, a[k], cur[k]);  // a_current = transform * a
                 if (METHOD == ICPX_TRIMMED) {
                     double best[QPT];
-                    if (have_seed) {
+                    bool searched = false;
+                    if constexpr (kChunkable) {
+                        if (chunked) {
+                            double bound[QPT];
+                            if (have_seed) {
+                                seed_bound<D, QPT>(cur, L, m, bound, pair);  // (the seed only bounds: the scan finds it again)
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < QPT; k++) bound[k] = __builtin_inf();
+                            }
+                            nn_lds_chunked<D, QPT>(cur, valid, L, m, m4, cbox, bound, best, pair);
+                            searched = true;
+                        }
+                    }
+                    if (searched) {
+                    } else if (have_seed) {
                         seed_bound<D, QPT>(cur, L, m, best, pair);
                         nn_filtered<D, QPT>(cur, L, m4, F, best, pair);
                     } else if (filter) nn_twomin<D, QPT>(cur, L, m4, F, best, pair);
                     else nn_lds<D, QPT>(cur, L, m4, best, pair);
-                    have_seed = filter;
+                    have_seed = filter || chunked;
 #pragma unroll
                     for (int k = 0; k < QPT; k++) cost[k] = valid[k] ? best[k] : 0.0;
                     // trimming step, trimmed.cpp:55-58: in the order (cost, point) keep the first new_n.
@@ -1127,7 +1166,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     }
 
     // ---- publish ----
-    if (filter && pb.seeds) {
+    if ((filter || chunked) && pb.seeds) {
 #pragma unroll
         for (int k = 0; k < QPT; k++)
             if (valid[k]) pb.seeds[s0 + tid + k * T] = pair[k];
