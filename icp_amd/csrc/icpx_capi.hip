@@ -352,6 +352,32 @@ int enqueue_prepass(int dim, int64_t n_pairs, int64_t m_max, int64_t m_total, co
     return ICPX_OK;
 }
 
+// The deferred sort of trimmed ICP2's matches (PairBatch::lazy_sort): one workgroup, pair 0 of a handle.
+// Dynamic LDS: 12 bytes x npad (npad = the power of two >= n).
+__global__ void __launch_bounds__(1024) pair_sort_matches_kernel(const int n, const int npad, PairState* __restrict__ st,
+                                                                 int64_t* __restrict__ m_point, int64_t* __restrict__ m_pair,
+                                                                 double* __restrict__ m_cost, const int32_t* __restrict__ pair_tmp) {
+    extern __shared__ __attribute__((aligned(16))) double sort_lds[];
+    if ((st->kd_flags & 16) == 0) return;  // (uniform: already sorted, or the matches of setup, which stay in point order)
+    uint64_t* skey = reinterpret_cast<uint64_t*>(sort_lds);
+    uint32_t* sval = reinterpret_cast<uint32_t*>(skey + npad);
+    const int T = blockDim.x, tid = threadIdx.x;
+    for (int i = tid; i < npad; i += T) {
+        skey[i] = i < n ? static_cast<uint64_t>(__double_as_longlong(m_cost[i])) : ~0ULL;
+        sval[i] = static_cast<uint32_t>(i);
+    }
+    __syncthreads();
+    bitonic_sort(skey, sval, npad, T);
+    for (int r = tid; r < n; r += T) {
+        const uint32_t pt = sval[r];
+        m_point[r] = pt;
+        m_pair[r] = pair_tmp[pt];
+        m_cost[r] = __longlong_as_double(static_cast<long long>(skey[r]));
+    }
+    __syncthreads();
+    if (tid == 0) st->kd_flags &= ~static_cast<uint64_t>(16);
+}
+
 // [kdnode m][kdpos m] (u16), then 16 bytes whose first word counts the pairs a launch stopped at a tie
 size_t kd_buffer_bytes(int64_t m_total) {
     const size_t pts = static_cast<size_t>(m_total > 0 ? m_total : 1);
@@ -499,6 +525,7 @@ void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
     pb.overlap_rate = h->prm.overlap_rate;
     pb.max_distance = h->prm.max_distance;
     pb.clock_to_s = di.clock_to_s;
+    pb.lazy_sort = 1;
     pb.kdnode = h->kd.as<uint16_t>();
     pb.kdpos = pb.kdnode + (h->m > 0 ? h->m : 1);
     pb.kd_paused = reinterpret_cast<int32_t*>(h->kd.as<char>() + kd_buffer_bytes(h->m) - 16);
@@ -1335,6 +1362,26 @@ int icpx_matches(icpx_handle h, int64_t* point, int64_t* pair, double* cost) {
     DeviceGuard g;
     ICPX_TRY(g.enter(h->device));
     if (h->large) return large_matches(h->lg, point, pair, cost);
+    if (h->method == ICPX_TRIMMED) {
+        // the kernels leave trimmed ICP2's matches in point order and marked; sorted by (cost, point) here (trimmed.cpp:55-56)
+        int npad = 2;
+        while (npad < n) npad <<= 1;
+        const size_t lds = 12 * static_cast<size_t>(npad);
+        static std::mutex mu;
+        static std::unordered_map<int, bool> attr_set;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!attr_set[h->device]) {
+                ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_sort_matches_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 2 * kPairMaxN));
+                attr_set[h->device] = true;
+            }
+        }
+        hipLaunchKernelGGL(pair_sort_matches_kernel, dim3(1), dim3(1024), lds, h->stream, static_cast<int>(n), npad,
+                           h->state.as<PairState>(), h->m_point.as<int64_t>(), h->m_pair.as<int64_t>(), h->m_cost.as<double>(),
+                           h->pair_tmp.as<int32_t>());
+        ICPX_HIP(hipGetLastError());
+    }
     if (point) ICPX_HIP(hipMemcpyAsync(point, h->m_point.p, sizeof(int64_t) * n, hipMemcpyDefault, h->stream));
     if (pair) ICPX_HIP(hipMemcpyAsync(pair, h->m_pair.p, sizeof(int64_t) * n, hipMemcpyDefault, h->stream));
     if (cost) ICPX_HIP(hipMemcpyAsync(cost, h->m_cost.p, sizeof(double) * n, hipMemcpyDefault, h->stream));

@@ -94,6 +94,8 @@ struct PairBatch {
     int32_t kd_takeover;       // this launch is that KD kernel: only paused pairs run, from where they stopped
                                // (and pairs deferred by the pruned kernel, bit 2 of kd_flags: from the beginning)
     int32_t defer_sparse;      // pruned kernels: hand pairs whose grid is a poor index (PairGrid::bad bit 1) to the kernel launched behind
+    int32_t lazy_sort;         // handles, trimmed ICP2: the matches are published in point order and marked (PairState::kd_flags
+                               // bit 4); icpx_matches sorts them by (cost, point) when they are asked for (pair_sort_matches_kernel)
     int32_t chunk_skip;        // trimmed ICP2, brute-force kernels: chunk-skipping exact search (nn_lds_chunked, icpx_filter.h);
                                // the launch reserved pair_lds_bytes_chunk (the boxes take the f32 copy's place)
 };
@@ -778,6 +780,18 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     const double* __restrict__ src = pb.src + s0 * D;
     const double* __restrict__ dst = pb.dst + d0 * D;
     PairState* st = pb.states + p;
+#ifdef ICPX_STATS
+    uint64_t vs0 = wall_clock64();
+#define ICPX_VSTAMP(slot_)                                                                             \
+    do {                                                                                               \
+        __syncthreads();                                                                               \
+        uint64_t vs1 = wall_clock64();                                                                 \
+        if (threadIdx.x == 0) atomicAdd(&g_icpx_stats[slot_], static_cast<unsigned long long>(vs1 - vs0)); \
+        vs0 = vs1;                                                                                     \
+    } while (0)
+#else
+#define ICPX_VSTAMP(slot_) do { } while (0)
+#endif
     constexpr bool kChunkable = D == 2 && METHOD == ICPX_TRIMMED && !KD;
     const bool chunked = kChunkable && pb.chunk_skip != 0;
     const bool filter = !KD && !chunked && pb.use_filter != 0 && !(D == 2 && METHOD == ICPX_VANILLA);
@@ -885,6 +899,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     for (int e = 0; e < XN; e++) X.m[e] = L.bc[e];
 
     double state_cost = 0.0;
+    ICPX_VSTAMP(12);  // staging, boxes, state
     if (do_setup) {
         // ---- method setup(): initial matches (2D) ----
         if (D == 2 && !empty) {
@@ -947,6 +962,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         }
     }
 
+    ICPX_VSTAMP(13);  // setup search + cost
     // ---- ICPDriver::converge loop, driver.h:63-69 ----
     uint64_t steps = 0;
     int exit_code = 0;
@@ -1165,6 +1181,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
         }
     }
 
+    ICPX_VSTAMP(14);  // loop
     // ---- publish ----
     if ((filter || chunked) && pb.seeds) {
 #pragma unroll
@@ -1188,14 +1205,18 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
                     pb.m_cost[s0 + tid + k * T] = cost[k];
                     pb.m_point[s0 + tid + k * T] = tid + k * T;
                 }
-        } else if (!sorted_matches) {
+        } else if (!sorted_matches || pb.lazy_sort != 0) {
+            // (lazy_sort: trimmed.cpp:55-56 leaves the matches sorted by cost; a converge() call rarely reads them, so the
+            // sort — 55 barrier-separated bitonic stages, 24 us for 1000 points — waits until icpx_matches asks)
 #pragma unroll
             for (int k = 0; k < QPT; k++)
                 if (valid[k]) {
                     pb.m_point[s0 + tid + k * T] = tid + k * T;
                     pb.m_pair[s0 + tid + k * T] = pair[k];
                     pb.m_cost[s0 + tid + k * T] = cost[k];
+                    if (sorted_matches) pb.pair_tmp[s0 + tid + k * T] = pair[k];
                 }
+            if (tid == 0) st->kd_flags = sorted_matches ? (st->kd_flags | 16) : (st->kd_flags & ~static_cast<uint64_t>(16));
         } else {
             // Trimmed leaves matches sorted by cost (trimmed.cpp:55-56): sort (cost, point) now
             const int npad = pb.lds_sort_cap;
@@ -1228,6 +1249,7 @@ ICPX_DEV int pair_body(const PairBatch& pb, const int p, const int do_setup, con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's stores are out before the hand-off
     __syncthreads();                                   // and LDS may be restaged by the next task
+    ICPX_VSTAMP(15);  // publish
     return exit_code;
 }
 

@@ -12,11 +12,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed,prune", [(3, "0"), (11, "0"), (3, "1"), (17, "1")])
-def test_fuzz_fused_kernels_against_oracle(seed, prune):
+@pytest.mark.parametrize("seed,prune,chunk", [(3, "0", "1"), (11, "0", "0"), (3, "1", "1"), (17, "1", "1"), (23, "0", "1")])
+def test_fuzz_fused_kernels_against_oracle(seed, prune, chunk):
     """prune = "1": handles and batches go through the grid-pruned kernels (icpx_prune.h);
-    "0": through the brute-force f32 filter + exact refinement."""
-    env = dict(os.environ, ICPX_PRUNE=prune, ICPX_PRUNE_HANDLES=prune)
+    "0": through the brute-force kernels — trimmed ICP2 with the chunk-skipping exact scan (chunk = "1", the default)
+    or, like the 3D methods, with the f32 filter + exact refinement (chunk = "0")."""
+    env = dict(os.environ, ICPX_PRUNE=prune, ICPX_PRUNE_HANDLES=prune, ICPX_CHUNK_SKIP=chunk)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_filter.py"), str(seed), "60"],
                          capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

@@ -572,6 +572,43 @@ def test_filtered_search_adversarial_inputs(icp, ob, prune_handles, knob):
                 assert np.array_equal(u, v), (kind, it)
 
 
+@pytest.mark.parametrize("chunk", ["1", "0"])
+def test_trimmed2d_chunk_skipping_search(icp, ob, scans, knob, chunk):
+    """Trimmed ICP2 in the brute-force kernels scans only the chunks of 32 consecutive targets some query of the wave
+    can reach (nn_lds_chunked, icpx_filter.h; "0": the f32 filter instead).  Matches (point, target index, cost) equal
+    the oracle's after begin and after every iteration on: a lidar scan in scan order (the coherent case), a cloud
+    sorted along x with every target duplicated in another chunk (exact ties across chunks: the lowest index must
+    win), points on a line, a shuffled cloud (every chunk needed), targets with NaN / inf coordinates."""
+    knob.set("ICPX_CHUNK_SKIP", chunk)
+    rng = np.random.default_rng(77)
+    cases = [("scan", *scans[1])]
+    t = rng.uniform(-5, 5, (600, 2))
+    t = t[np.argsort(t[:, 0])]
+    t = np.concatenate([t, t])                      # target j and j + 600 coincide
+    cases.append(("sorted_dups", t[rng.integers(0, 600, 900)] + rng.normal(0, 0.02, (900, 2)), t))
+    t = np.zeros((700, 2))
+    t[:, 0] = np.sort(rng.uniform(-5, 5, 700))
+    cases.append(("line", t[rng.integers(0, 700, 500)] + [0.0, 0.3], t))
+    t = rng.uniform(-5, 5, (1000, 2))
+    cases.append(("shuffled", t[rng.permutation(1000)[:800]] + rng.normal(0, 0.05, (800, 2)), t))
+    t = scans[2][1].copy()
+    t[5] = [np.nan, 0.1]
+    t[40] = [np.inf, 0.0]
+    t[41] = [0.3, -np.inf]
+    t[300] = [np.nan, np.nan]
+    cases.append(("nonfinite", scans[2][0], t))
+    for name, s, t in cases:
+        x, o = icp.ICP2.from_method("trimmed"), dev_oracle(ob, 2, "trimmed")
+        x.begin(s, t)
+        o.begin(s, t)
+        for it in range(5):
+            for u, v in zip(x.get_matches_arrays(), o.get_matches()):
+                assert np.array_equal(u, v, equal_nan=True), (name, it)
+            assert np.array_equal(x.current_transform(), o.current_transform(), equal_nan=True), (name, it)
+            x.iterate()
+            o.iterate()
+
+
 def test_feature_aware_matches_oracle(icp, ob, scans):
     """FeatureAware (ICP2) on the multi-kernel path — features, normalised feature
     distances, weighted-cost matches, trimming, Kabsch — bit-exact against the oracle in device

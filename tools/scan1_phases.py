@@ -20,4 +20,6 @@ it = r.iteration_count
 print("iterations", it)
 for s, name in ((8, "search"), (9, "selection"), (10, "sums"), (11, "kabsch+broadcast")):
     print(f"  {name:18s} {v[s] / 100.0 / it:7.2f} us per iteration")
+for s, name in ((12, "staging+boxes+state"), (13, "setup search+cost"), (14, "loop"), (15, "publish")):
+    print(f"  {name:22s} {v[s] / 100.0:7.2f} us per call")
 print("all slots", [int(x) for x in v])
