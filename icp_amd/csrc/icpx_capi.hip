@@ -66,6 +66,7 @@ bool set_knob(Knobs& k, const char* name, const char* value) {
     else if (n == "ICPX_GRID_SEED") k.grid_seed = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_DEFER_SPARSE") k.defer_sparse = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_CHUNK_SKIP") k.chunk_skip = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_ZERO_COPY") k.zero_copy = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_GRID_DENSITY") k.grid_density = (value && iv >= 1 && iv <= 1000) ? iv : 0;
     else if (n == "ICPX_GRID_SD") k.grid_sd = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_TILE_MIN") k.tile_min = (value && iv >= 64 && iv <= 3072) ? (iv & ~3) : 0;
@@ -92,7 +93,7 @@ Knobs& knobs() {
     static Knobs k;
     static const bool from_env = [] {
         for (const char* n : {"ICPX_PRUNE", "ICPX_FILTER", "ICPX_SCHED", "ICPX_SCHED_STEPS", "ICPX_PRUNE_HANDLES",
-                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_DEFER_SPARSE", "ICPX_CHUNK_SKIP", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
+                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_DEFER_SPARSE", "ICPX_CHUNK_SKIP", "ICPX_ZERO_COPY", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
             if (const char* v = std::getenv(n)) set_knob(k, n, v);
         return true;
     }();
@@ -464,6 +465,17 @@ struct icpx_ctx {
     DevBuf kd;                           // kd rule: [kdnode m][kdpos m] (u16) and the paused-pairs word behind them
     bool use_cert = false;
     LargeIcp* lg = nullptr;
+    // Host inputs of a fused pair are not copied to the device: they go into one pinned, device-visible arena
+    // ([offsets][guess][source][target][result]) that the kernels read and write across the bus — a scan pair is 30 KB, and
+    // the four staged copies, their stream synchronisation and the copy back were 50 us of a 140 us call.
+    char* stage = nullptr;
+    size_t stage_cap = 0;
+    bool staged = false;                 // this begin's inputs live in the arena (else: in src / dst / off / guess / out)
+    const double* p_src = nullptr;
+    const double* p_dst = nullptr;
+    const double* p_guess = nullptr;
+    const int64_t* p_off = nullptr;
+    icpx_state* p_out = nullptr;
 };
 
 namespace {
@@ -473,33 +485,79 @@ int check_handle(icpx_handle h) {
     return ICPX_OK;
 }
 
+// plain host memory (or pinned / registered host memory)?  Device and managed pointers keep the device-side copies.
+bool is_host_pointer(const void* p) {
+    if (!p) return true;
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // (unregistered host memory reports an error)
+        return true;
+    }
+    return attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeUnregistered;
+}
+
+constexpr size_t kStageMaxBytes = size_t(8) << 20;
+
 int upload_pair(icpx_ctx* h, const double* source, int64_t n, const double* target, int64_t m,
                 const double* guess) {
     const int D = h->dim, XN = (D + 1) * (D + 1);
-    ICPX_TRY(h->src.reserve(sizeof(double) * D * (n > 0 ? n : 1)));
-    ICPX_TRY(h->dst.reserve(sizeof(double) * D * (m > 0 ? m : 1)));
     ICPX_TRY(h->cur.reserve(sizeof(double) * D * (n > 0 ? n : 1)));
-    ICPX_TRY(h->off.reserve(sizeof(int64_t) * 4));
-    ICPX_TRY(h->guess.reserve(sizeof(double) * 16));
     ICPX_TRY(h->m_point.reserve(sizeof(int64_t) * (n > 0 ? n : 1)));
     ICPX_TRY(h->m_pair.reserve(sizeof(int64_t) * (n > 0 ? n : 1)));
     ICPX_TRY(h->m_cost.reserve(sizeof(double) * (n > 0 ? n : 1)));
     ICPX_TRY(h->pair_tmp.reserve(sizeof(int32_t) * (n > 0 ? n : 1)));
     ICPX_TRY(h->seeds.reserve(sizeof(int32_t) * (n > 0 ? n : 1)));
     ICPX_TRY(h->state.reserve(sizeof(PairState)));
-    ICPX_TRY(h->out.reserve(sizeof(icpx_state)));
     ICPX_TRY(h->kd.reserve(kd_buffer_bytes(m)));
-    if (n > 0) ICPX_HIP(hipMemcpyAsync(h->src.p, source, sizeof(double) * D * n, hipMemcpyDefault, h->stream));
-    if (m > 0) ICPX_HIP(hipMemcpyAsync(h->dst.p, target, sizeof(double) * D * m, hipMemcpyDefault, h->stream));
-    int64_t off[4] = {0, n, 0, m};
-    ICPX_HIP(hipMemcpyAsync(h->off.p, off, sizeof(off), hipMemcpyHostToDevice, h->stream));
-    ICPX_HIP(hipMemcpyAsync(h->guess.p, guess, sizeof(double) * XN, hipMemcpyDefault, h->stream));
-    // the pageable host staging above must be consumed before `off` goes out of scope
-    ICPX_HIP(hipStreamSynchronize(h->stream));
+    const size_t src_bytes = sizeof(double) * D * static_cast<size_t>(n), dst_bytes = sizeof(double) * D * static_cast<size_t>(m);
+    const size_t o_off = 0, o_guess = 32, o_out = o_guess + 128, o_src = (o_out + sizeof(icpx_state) + 63) & ~size_t(63);
+    const size_t o_dst = (o_src + src_bytes + 63) & ~size_t(63), total = o_dst + dst_bytes + 64;
+    const int64_t off[4] = {0, n, 0, m};
+    h->staged = knobs().zero_copy != 0 && total <= kStageMaxBytes && is_host_pointer(source) && is_host_pointer(target) &&
+                is_host_pointer(guess);
+    if (h->staged) {
+        // (kernels of an earlier begin may still be reading the arena: begin / iterate do not wait for theirs)
+        ICPX_HIP(hipStreamSynchronize(h->stream));
+        if (total > h->stage_cap) {
+            if (h->stage) ICPX_HIP(hipHostFree(h->stage));
+            h->stage = nullptr;
+            h->stage_cap = 0;
+            const size_t want = total + total / 4 + 4096;
+            ICPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->stage), want, hipHostMallocPortable | hipHostMallocMapped));
+            h->stage_cap = want;
+        }
+        std::memcpy(h->stage + o_off, off, sizeof(off));
+        std::memcpy(h->stage + o_guess, guess, sizeof(double) * XN);
+        if (n > 0) std::memcpy(h->stage + o_src, source, src_bytes);
+        if (m > 0) std::memcpy(h->stage + o_dst, target, dst_bytes);
+        h->p_off = reinterpret_cast<const int64_t*>(h->stage + o_off);
+        h->p_guess = reinterpret_cast<const double*>(h->stage + o_guess);
+        h->p_out = reinterpret_cast<icpx_state*>(h->stage + o_out);
+        h->p_src = reinterpret_cast<const double*>(h->stage + o_src);
+        h->p_dst = reinterpret_cast<const double*>(h->stage + o_dst);
+    } else {
+        ICPX_TRY(h->src.reserve(sizeof(double) * D * (n > 0 ? n : 1)));
+        ICPX_TRY(h->dst.reserve(sizeof(double) * D * (m > 0 ? m : 1)));
+        ICPX_TRY(h->off.reserve(sizeof(int64_t) * 4));
+        ICPX_TRY(h->guess.reserve(sizeof(double) * 16));
+        ICPX_TRY(h->out.reserve(sizeof(icpx_state)));
+        if (n > 0) ICPX_HIP(hipMemcpyAsync(h->src.p, source, src_bytes, hipMemcpyDefault, h->stream));
+        if (m > 0) ICPX_HIP(hipMemcpyAsync(h->dst.p, target, dst_bytes, hipMemcpyDefault, h->stream));
+        ICPX_HIP(hipMemcpyAsync(h->off.p, off, sizeof(off), hipMemcpyHostToDevice, h->stream));
+        ICPX_HIP(hipMemcpyAsync(h->guess.p, guess, sizeof(double) * XN, hipMemcpyDefault, h->stream));
+        // the pageable host staging above must be consumed before `off` goes out of scope
+        ICPX_HIP(hipStreamSynchronize(h->stream));
+        h->p_off = h->off.as<int64_t>();
+        h->p_guess = h->guess.as<double>();
+        h->p_out = h->out.as<icpx_state>();
+        h->p_src = h->src.as<double>();
+        h->p_dst = h->dst.as<double>();
+    }
     h->n = n;
     h->m = m;
     if (h->geom.prune)
-        ICPX_TRY(enqueue_prepass(D, 1, m, m, h->dst.as<double>(), h->off.as<int64_t>() + 2, h->tperm, h->grids, h->cstart,
+        ICPX_TRY(enqueue_prepass(D, 1, m, m, h->p_dst, h->p_off + 2, h->tperm, h->grids, h->cstart,
                                  h->hcert, &h->use_cert, h->stream));
     return ICPX_OK;
 }
@@ -508,11 +566,11 @@ void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
     std::memset(&pb, 0, sizeof(pb));
     pb.dim = h->dim;
     pb.method = h->method;
-    pb.src = h->src.as<double>();
-    pb.src_off = h->off.as<int64_t>();
-    pb.dst = h->dst.as<double>();
-    pb.dst_off = h->off.as<int64_t>() + 2;
-    pb.guesses = h->guess.as<double>();
+    pb.src = h->p_src;
+    pb.src_off = h->p_off;
+    pb.dst = h->p_dst;
+    pb.dst_off = h->p_off + 2;
+    pb.guesses = h->p_guess;
     pb.cur = h->cur.as<double>();
     pb.m_point = h->m_point.as<int64_t>();
     pb.m_pair = h->m_pair.as<int64_t>();
@@ -520,7 +578,7 @@ void fill_batch(icpx_ctx* h, PairBatch& pb, const DeviceInfo& di) {
     pb.pair_tmp = h->pair_tmp.as<int32_t>();
     pb.seeds = h->seeds.as<int32_t>();
     pb.states = h->state.as<PairState>();
-    pb.out_states = h->out.as<icpx_state>();
+    pb.out_states = h->p_out;
     pb.crit = no_criteria();
     pb.overlap_rate = h->prm.overlap_rate;
     pb.max_distance = h->prm.max_distance;
@@ -633,8 +691,13 @@ int converge_impl(icpx_handle h, const double* source, int64_t n, const double* 
     pb.max_steps = UINT64_MAX;
     pb.host_elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ICPX_TRY(launch_pairs(pb, 1, h->geom, h->stream));
-    ICPX_HIP(hipMemcpyAsync(out, h->out.p, sizeof(icpx_state), hipMemcpyDefault, h->stream));
-    ICPX_HIP(hipStreamSynchronize(h->stream));
+    if (h->staged) {
+        ICPX_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(out, h->p_out, sizeof(icpx_state));  // (the kernel wrote it into the arena)
+    } else {
+        ICPX_HIP(hipMemcpyAsync(out, h->p_out, sizeof(icpx_state), hipMemcpyDefault, h->stream));
+        ICPX_HIP(hipStreamSynchronize(h->stream));
+    }
     h->begun = true;
     return ICPX_OK;
 }
@@ -1247,6 +1310,7 @@ int icpx_destroy(icpx_handle h) {
                       &h->m_cost, &h->pair_tmp, &h->seeds, &h->state, &h->out, &h->tperm, &h->grids, &h->cstart, &h->hcert, &h->kd})
         b->release();
     if (h->lg) large_destroy(h->lg);
+    if (h->stage) (void)hipHostFree(h->stage);
     delete h;
     return ICPX_OK;
     });

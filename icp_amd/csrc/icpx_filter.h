@@ -154,7 +154,39 @@ ICPX_DEV void nn_lds_chunked(const double (&q)[QPT][D], const bool (&valid)[QPT]
     for (int k = 0; k < QPT; k++) {
         double bst = __builtin_inf();
         int bblk = 0;
-        const double bnd = bound[k];
+        double bnd = bound[k];
+        if (__any(valid[k] && !(bnd < __builtin_inf()))) {
+            // no seed (a pair's first search): every lane looks through the chunk whose box is nearest to its query —
+            // its own addresses, no broadcast — and takes the smallest distance there as its bound.  Without it the
+            // scan below meets the query's neighbourhood only when it gets there, half the cloud later on average.
+            double lbmin = __builtin_inf();
+            int cmin = 0;
+            for (int c = 0; c < nch; c++) {
+                double lb = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const double lo = cb[(c * 2 + 0) * D + d], hi = cb[(c * 2 + 1) * D + d];
+                    const double g = __builtin_fmax(__builtin_fmax(lo - q[k][d], q[k][d] - hi), 0.0);
+                    lb = d == 0 ? g * g : lb + g * g;
+                }
+                const bool lt = lb < lbmin;
+                lbmin = lt ? lb : lbmin;
+                cmin = lt ? c : cmin;
+            }
+            double pb_ = __builtin_inf();
+            const int j1 = min((cmin + 1) * kChunk, m);
+            for (int j = cmin * kChunk; j < j1; j++) {
+                double df = L.t[0][j] - q[k][0];
+                double acc = df * df;
+#pragma unroll
+                for (int d = 1; d < D; d++) {
+                    df = L.t[d][j] - q[k][d];
+                    acc = acc + df * df;
+                }
+                pb_ = __builtin_fmin(pb_, acc);
+            }
+            bnd = __builtin_fmin(bnd, pb_);  // (NaN bound: the probe's)
+        }
         for (int c = 0; c < nch; c++) {
             double lb = 0.0;
 #pragma unroll

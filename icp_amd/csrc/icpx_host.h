@@ -44,6 +44,7 @@ struct Knobs {
     std::atomic<int> tile_wgs{0};        // ICPX_TILE_WGS: workgroups the tiled search aims at (0 = built-in 768)
     std::atomic<int> tile_min{0};        // ICPX_TILE_MIN: fewest targets per split of the tiled search (0 = built-in 512)
     std::atomic<int> grid_density{0};    // ICPX_GRID_DENSITY: targets per cell of the HBM grid in tenths (0 = built-in 20)
+    std::atomic<int> zero_copy{1};       // ICPX_ZERO_COPY: 0 = host inputs of a fused pair are copied to the device (four staged copies)
     std::atomic<int> chunk_skip{1};      // ICPX_CHUNK_SKIP: 0 = trimmed ICP2's brute-force kernels search with the f32 filter
     std::atomic<int> defer_sparse{1};    // ICPX_DEFER_SPARSE: 0 = pruned kernels keep the pairs whose grid is a poor index
     std::atomic<int> grid_sd{1};         // ICPX_GRID_SD: 0 = no sorted-domain copy of the running cloud for the 3D grid search (LargeIcp::sd)
