@@ -423,6 +423,21 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
                                   "note": "examined records mostly come from L2 (neighbouring queries share cells): the "
                                           "algorithmic figure counts them all; measured HBM bytes are in profiles/ "
                                           "(rNN_counters.json, grid_nn_kernel)"}}
+    # f3: the OPT-IN f32 correspondence mode on the same clouds (16-byte f32 records, candidates evaluated in f32;
+    # not reference arithmetic, not part of `value`): one correspondence step, build + query, and how often it returns
+    # the f64 search's target
+    idx32 = torch.zeros_like(idx)
+    icp_amd.nearest_neighbors(d_q, d_t, icp_amd.NN_GRID_F32, device=local_rank, stream=stream, out_idx=idx32, out_d2=d2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        icp_amd.nearest_neighbors(d_q, d_t, icp_amd.NN_GRID_F32, device=local_rank, stream=stream, out_idx=idx32, out_d2=d2)
+    torch.cuda.synchronize()
+    dt32 = (time.perf_counter() - t0) / 5
+    ex["c4_f32_grid_nn_1m_build_plus_query_ms"] = dt32 * 1e3
+    ex["c4_f32_grid_nn_1m_queries_per_s"] = len(src) / dt32
+    ex["c4_f32_same_target_as_f64"] = float((idx32 == idx).double().mean().item())
+    del idx32
     # config 4, clustered variant (points on 64 planes: most cells empty) — one correspondence step, build + query
     srcc, tgtc, _, _ = synth.config4(1_000_000, clustered=True)
     d_qc, d_tc = torch.from_numpy(srcc).to(dev), torch.from_numpy(tgtc).to(dev)
@@ -463,6 +478,21 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
     # time of 50 iterations, not of a converged registration
     ex["c4_converge_stopped_by"] = ("max_iterations (%d): not converged" % MAX_ITER) if r4.iteration_count >= MAX_ITER \
         else "transform tolerance"
+    # the same converge with the opt-in f32 correspondence mode (Config nn = "grid_f32"; sums, Kabsch, termination f64)
+    cfg32 = icp_amd.Config()
+    cfg32.set("nn", "grid_f32")
+    drv32 = icp_amd.ICPDriver(icp_amd.ICP3.from_method("vanilla", cfg32, device=local_rank))
+    drv32.set_max_iterations(MAX_ITER)
+    drv32.set_transform_tolerance(*TOL)
+    r32 = drv32.converge(d_q, d_t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r32 = drv32.converge(d_q, d_t)
+    torch.cuda.synchronize()
+    ex["c4_f32_converge_ms"] = (time.perf_counter() - t0) * 1e3
+    ex["c4_f32_converge_iterations"] = r32.iteration_count
+    ex["c4_f32_converge_max_abs_transform_diff_vs_f64"] = float(np.abs(np.asarray(r32.transform) - np.asarray(r4.transform)).max())
+    del drv32
     # roofline of one iteration of this path (HBM): what an iteration must move at least — the running cloud read and
     # written (48 B per point), the matched target's coordinates and index written for the sums (32 B per point), the
     # target cloud read once (24 B per target); the examined grid records (L2 mostly) are on top and not counted

@@ -7,8 +7,8 @@ benchmarks use (synth.py).
 """
 from .api import (ICP2, ICP3, Config, ConvergenceState, ICPDriver, Match, converge_batch,
                   make_criteria, nearest_neighbors, nearest_neighbors_kdtree)
-from ._lib import IcpxError, NN_AUTO, NN_BRUTE, NN_GRID, NN_BVH, TRIMMED, VANILLA
+from ._lib import IcpxError, NN_AUTO, NN_BRUTE, NN_GRID, NN_BVH, NN_GRID_F32, TRIMMED, VANILLA
 
 __all__ = ["ICP2", "ICP3", "Config", "ConvergenceState", "ICPDriver", "Match", "converge_batch",
-           "make_criteria", "nearest_neighbors", "nearest_neighbors_kdtree", "IcpxError", "NN_AUTO", "NN_BRUTE", "NN_GRID", "NN_BVH",
+           "make_criteria", "nearest_neighbors", "nearest_neighbors_kdtree", "IcpxError", "NN_AUTO", "NN_BRUTE", "NN_GRID", "NN_BVH", "NN_GRID_F32",
            "TRIMMED", "VANILLA"]

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libicpx.so")
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_NO_DEVICE = range(7)
 VANILLA, TRIMMED, FEATURE_AWARE = 0, 1, 2
 FLAG_MATCH_TRANSFORMED, FLAG_FILL_MATCHES, FLAG_APPLY_GUESS = 1, 2, 4
-NN_AUTO, NN_BRUTE, NN_GRID, NN_BVH = 0, 1, 2, 3
+NN_AUTO, NN_BRUTE, NN_GRID, NN_BVH, NN_GRID_F32 = 0, 1, 2, 3, 4
 HAS_MIN_ITER, HAS_MAX_ITER, HAS_STOP_COST, HAS_REL_TOL = 1, 2, 4, 8
 HAS_ABS_TOL, HAS_TRANSFORM_TOL, HAS_TIME_LIMIT = 16, 32, 64
 

@@ -96,7 +96,7 @@ class ICP:
                    (L.FLAG_FILL_MATCHES if config.get("fill_matches", 0) else 0) |
                    (L.FLAG_APPLY_GUESS if config.get("apply_guess", 0) else 0))
         # optional, non-reference key: "nn" = "auto" | "brute" | "grid"
-        names = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID, "bvh": L.NN_BVH}
+        names = {"auto": L.NN_AUTO, "brute": L.NN_BRUTE, "grid": L.NN_GRID, "bvh": L.NN_BVH, "grid_f32": L.NN_GRID_F32}
         nn_name = config.get("nn", "")
         if nn_name and nn_name not in names:
             raise ValueError(f"Config 'nn' must be one of {sorted(names)}")

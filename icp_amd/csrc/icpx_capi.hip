@@ -616,7 +616,7 @@ int begin_common(icpx_ctx* h, const double* source, int64_t n, const double* tar
     // robust path; ICPX_PRUNE_HANDLES=1 selects the pruned kernels (then for every size that fits; tests run both).
     const bool prune_handles = knobs().prune_handles != 0;
     const bool fits = fused_fits(h->dim, h->method, n, m, &h->geom, true, prune_handles);
-    bool fused = h->prm.nn_mode != ICPX_NN_GRID && h->prm.nn_mode != ICPX_NN_BVH && fits &&
+    bool fused = h->prm.nn_mode != ICPX_NN_GRID && h->prm.nn_mode != ICPX_NN_GRID_F32 && h->prm.nn_mode != ICPX_NN_BVH && fits &&
                  (h->geom.prune || static_cast<double>(n) * static_cast<double>(m) <= single_max) &&
                  h->method != ICPX_FEATURE_AWARE &&  // feature_aware and the opt-in corrected modes run on
                  h->prm.flags == 0;                  // the multi-kernel path only
@@ -1281,7 +1281,7 @@ int icpx_create(int dim, int method, const icpx_params* params, icpx_handle* out
     icpx_params prm;
     icpx_default_params(&prm);
     if (params) prm = *params;
-    if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_BVH)
+    if (prm.nn_mode < ICPX_NN_AUTO || prm.nn_mode > ICPX_NN_GRID_F32)
         return fail(ICPX_ERR_INVALID, "unknown nn_mode %d", prm.nn_mode);
     if (prm.flags < 0 || prm.flags > 7) return fail(ICPX_ERR_INVALID, "unknown flags %d", prm.flags);
     int dev = 0;
@@ -1520,6 +1520,7 @@ int icpx_nn_grid_profile(int dim, const double* queries, int64_t n, const double
     Workspace& ws = workspace(dev, static_cast<hipStream_t>(stream_));
     std::lock_guard<std::mutex> lk(ws.mu);
     if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
+    grid_set_f32(ws.grid, false);
     return grid_profile(ws.grid, dim, queries, n, targets, m, static_cast<hipStream_t>(stream_), out);
     });
 }
@@ -1573,7 +1574,9 @@ static int nn_impl(int dim, const double* queries, int64_t n, const double* targ
     return guarded([&]() -> int {
     if (dim != 2 && dim != 3) return fail(ICPX_ERR_INVALID, "dim must be 2 or 3 (got %d)", dim);
     if (n < 0 || m < 0) return fail(ICPX_ERR_INVALID, "negative cloud size");
-    if (mode < ICPX_NN_AUTO || mode > ICPX_NN_BVH) return fail(ICPX_ERR_INVALID, "unknown nn mode %d", mode);
+    if (mode < ICPX_NN_AUTO || mode > ICPX_NN_GRID_F32) return fail(ICPX_ERR_INVALID, "unknown nn mode %d", mode);
+    if (kd && mode == ICPX_NN_GRID_F32)
+        return fail(ICPX_ERR_UNSUPPORTED, "the f32 grid mode gives up index parity: it has no kd-tree tie rule");
     if (n == 0) return ICPX_OK;
     if (!queries || (m > 0 && !targets)) return fail(ICPX_ERR_INVALID, "null queries/targets");
     if (n > INT32_MAX / 4 || m > INT32_MAX / 4) return fail(ICPX_ERR_UNSUPPORTED, "cloud too large");
@@ -1625,7 +1628,7 @@ static int nn_impl(int dim, const double* queries, int64_t n, const double* targ
     }
     const KdTies* tp = (kd && m > 0) ? &ties : nullptr;
 
-    bool use_grid = mode == ICPX_NN_GRID ||
+    bool use_grid = mode == ICPX_NN_GRID || mode == ICPX_NN_GRID_F32 ||
                     (mode == ICPX_NN_AUTO && static_cast<double>(n) * static_cast<double>(m) > 512.0 * 1024 * 1024);  // measured crossover of one build + query: ~3e4 x 3e4
     if (m == 0) use_grid = false;
     if (m == 0) {
@@ -1636,6 +1639,7 @@ static int nn_impl(int dim, const double* queries, int64_t n, const double* targ
         ICPX_TRY(bvh_nn_oneshot(ws.bvh, dim, d_q, n, d_t, m, d_idx, d_d2, stream, tp));
     } else if (use_grid) {
         if (!ws.grid) ICPX_TRY(grid_create(&ws.grid));
+        grid_set_f32(ws.grid, mode == ICPX_NN_GRID_F32);
         if (mode == ICPX_NN_AUTO && !ws.bvh) ICPX_TRY(bvh_create(&ws.bvh));
         ICPX_TRY(grid_nn_oneshot(ws.grid, dim, d_q, n, d_t, m, d_idx, d_d2, stream, mode == ICPX_NN_AUTO ? ws.bvh : nullptr, tp));
     } else {

@@ -31,6 +31,67 @@ struct __attribute__((aligned(16))) GridRec {
     int64_t idx;
 };
 
+// Opt-in f32 correspondence mode (ICPX_NN_GRID_F32; SURVEY 8 f3 — NOT reference arithmetic, never the default):
+// 16-byte records with the coordinates relative to the grid's lower corner, rounded to f32.  The searches below are
+// templates over the record type; with GridRec32 a candidate's squared distance is evaluated in f32 (FMA) against the
+// query moved by the same corner and rounded to f32, then widened — every bound, cell range and stopping test stays
+// the f64 code on the f64 query.  Half the record bytes and about a third of the arithmetic per candidate; the
+// returned target is the nearest one up to that rounding (two targets whose distances differ by less than ~2^-21 of
+// the cloud's extent may swap), so index parity with the reference is given up — which is why it is opt-in.
+struct __attribute__((aligned(16))) GridRec32 {
+    float x, y, z;
+    int idx;
+};
+
+template <typename Rec>
+struct RecTraits;
+template <>
+struct RecTraits<GridRec> {
+    using coord = double;
+    static constexpr bool f32 = false;
+    static ICPX_DEV const double* query(const double* q, const float*) { return q; }
+};
+template <>
+struct RecTraits<GridRec32> {
+    using coord = float;
+    static constexpr bool f32 = true;
+    static ICPX_DEV const float* query(const double*, const float* q32) { return q32; }
+};
+
+// the squared distance as the search computes it: the reference's f64 expression (trimmed.cpp:101, kdtree.h:124) ...
+template <int D>
+ICPX_DEV double d2_eval(const double x, const double y, const double z, const double* q) {
+    double df = x - q[0];
+    double dist = df * df;
+    df = y - q[1];
+    dist = dist + df * df;
+    if (D == 3) {
+        df = z - q[2];
+        dist = dist + df * df;
+    }
+    return dist;
+}
+// ... or, in the f32 mode, three f32 subtractions and FMAs
+template <int D>
+ICPX_DEV double d2_eval(const float x, const float y, const float z, const float* q) {
+    float df = x - q[0];
+    float dist = df * df;
+    df = y - q[1];
+    dist = __builtin_fmaf(df, df, dist);
+    if (D == 3) {
+        df = z - q[2];
+        dist = __builtin_fmaf(df, df, dist);
+    }
+    return static_cast<double>(dist);
+}
+
+// the query as the f32 records see it
+template <int D>
+ICPX_DEV void query_f32(const double* lo, const double* q, float* q32) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) q32[d] = d < D ? static_cast<float>(q[d] - lo[d]) : 0.0f;
+}
+
 // order-preserving map f64 -> u64 (for atomicMin / atomicMax on coordinates)
 ICPX_DEV unsigned long long f64_key(double v) {
     unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
@@ -235,19 +296,26 @@ __global__ void __launch_bounds__(256) grid_scan_local_kernel(const int* __restr
     if (blockIdx.x == gridDim.x - 1 && tid == 255) start[ncell] = totals[gridDim.x];
 }
 
-template <int D>
+template <int D, typename Rec = GridRec>
 __global__ void grid_scatter_kernel(const double* __restrict__ t, int64_t m, const int* __restrict__ cell_id,
                                     const int* __restrict__ start, int* __restrict__ cursor,
-                                    GridRec* __restrict__ recs) {
+                                    Rec* __restrict__ recs, const GridParams gp = GridParams{}) {
     int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= m) return;
     int c = cell_id[j];
     int pos = start[c] + atomicAdd(&cursor[c], 1);
-    GridRec r;
-    r.x = t[j * D + 0];
-    r.y = t[j * D + 1];
-    r.z = D == 3 ? t[j * D + 2] : 0.0;
-    r.idx = j;
+    Rec r;
+    if constexpr (RecTraits<Rec>::f32) {
+        r.x = static_cast<float>(t[j * D + 0] - gp.lo[0]);
+        r.y = static_cast<float>(t[j * D + 1] - gp.lo[1]);
+        r.z = D == 3 ? static_cast<float>(t[j * D + 2] - gp.lo[2]) : 0.0f;
+        r.idx = static_cast<int>(j);
+    } else {
+        r.x = t[j * D + 0];
+        r.y = t[j * D + 1];
+        r.z = D == 3 ? t[j * D + 2] : 0.0;
+        r.idx = j;
+    }
     recs[pos] = r;
 }
 
@@ -258,9 +326,11 @@ __global__ void grid_scatter_kernel(const double* __restrict__ t, int64_t m, con
 // TIES (all searches of this file): tie |= another, non-coincident target lies within kKdNearUlps of the minimum
 // (icpx_kd.h; cloud = the targets in cloud order).  The stopping tests leave unvisited only what is farther than
 // (1 + 2^-41) times the best, so every tie partner is among the evaluated records.
-template <int D, int NR, bool TIES = false>
-ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, const int (&kb)[NR], const int (&ke)[NR],
-                             double& best, int& bidx, int& visited, int& tie, const double* __restrict__ cloud) {
+template <int D, int NR, bool TIES = false, typename Rec = GridRec>
+ICPX_DEV void grid_scan_rows(const Rec* __restrict__ recs, const double* q, const int (&kb)[NR], const int (&ke)[NR],
+                             double& best, int& bidx, int& visited, int& tie, const double* __restrict__ cloud,
+                             const float* q32 = nullptr) {
+    const auto* qc = RecTraits<Rec>::query(q, q32);
     constexpr int kStep = 4;  // records in flight per lane (8: more registers, fewer waves, no gain — measured)
     int pre[NR], off[NR];
     int total = 0;
@@ -271,7 +341,7 @@ ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, 
         total += ke[t] - kb[t];
     }
     for (int r0 = 0; r0 < total; r0 += kStep) {
-        GridRec rec[kStep];
+        Rec rec[kStep];
 #pragma unroll
         for (int u = 0; u < kStep; u++) {
             const int r = r0 + u < total ? r0 + u : total - 1;
@@ -282,16 +352,9 @@ ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, 
         }
 #pragma unroll
         for (int u = 0; u < kStep; u++) {
-            double df = rec[u].x - q[0];
-            double dist = df * df;
-            df = rec[u].y - q[1];
-            dist = dist + df * df;
-            if (D == 3) {
-                df = rec[u].z - q[2];
-                dist = dist + df * df;
-            }
+            const double dist = d2_eval<D>(rec[u].x, rec[u].y, rec[u].z, qc);
             const int j = static_cast<int>(rec[u].idx);
-            const double cc[3] = {rec[u].x, rec[u].y, rec[u].z};
+            const double cc[3] = {static_cast<double>(rec[u].x), static_cast<double>(rec[u].y), static_cast<double>(rec[u].z)};
             nn_take<TIES, D>(r0 + u < total, dist, j, cc, cloud, best, bidx, tie);
         }
     }
@@ -305,10 +368,11 @@ ICPX_DEV void grid_scan_rows(const GridRec* __restrict__ recs, const double* q, 
 // slabs exactly as in the shells' stopping test (same slack), so a row or cell is skipped only when everything in
 // it is strictly farther than the current best; cell ranges use cell_coord, the (monotone) function that placed
 // the targets.  best only shrinks, so everything at most as far as the final best is evaluated.
-template <int D, bool TIES = false>
-ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+template <int D, bool TIES = false, typename Rec = GridRec>
+ICPX_DEV void grid_ball_scan(const GridParams& gp, const Rec* __restrict__ recs, const int* __restrict__ start,
                              const double* q, const int (&c)[3], double& best, int& bidx, int& visited, int& tie,
-                             const double* __restrict__ cloud) {
+                             const double* __restrict__ cloud, const float* q32 = nullptr) {
+    const auto* qc = RecTraits<Rec>::query(q, q32);
     const double down = 0.99999999999909051;  // 1 - 2^-40
     double slack[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -343,21 +407,14 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ r
             const int row = (z * gp.g[1] + y) * gp.g[0];
             const int kb = start[row + x0], ke = start[row + x1 + 1];
             for (int k0 = kb; k0 < ke; k0 += 4) {
-                GridRec rec[4];
+                Rec rec[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) rec[u] = recs[k0 + u < ke ? k0 + u : ke - 1];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    double df = rec[u].x - q[0];
-                    double dist = df * df;
-                    df = rec[u].y - q[1];
-                    dist = dist + df * df;
-                    if (D == 3) {
-                        df = rec[u].z - q[2];
-                        dist = dist + df * df;
-                    }
+                    const double dist = d2_eval<D>(rec[u].x, rec[u].y, rec[u].z, qc);
                     const int j = static_cast<int>(rec[u].idx);
-                    const double cc[3] = {rec[u].x, rec[u].y, rec[u].z};
+                    const double cc[3] = {static_cast<double>(rec[u].x), static_cast<double>(rec[u].y), static_cast<double>(rec[u].z)};
                     nn_take<TIES, D>(k0 + u < ke, dist, j, cc, cloud, best, bidx, tie);
                 }
             }
@@ -372,10 +429,10 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const GridRec* __restrict__ r
 // tested and bounded exactly as in grid_ball_scan, but all their bounds are fetched before the first record (the
 // walk is a chain of memory latencies).  The candidate itself is among the visited targets, so the result is the
 // (d2, index) minimum over the whole cloud: what grid_query returns.
-template <int D, bool TIES = false>
-ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+template <int D, bool TIES = false, typename Rec = GridRec>
+ICPX_DEV void grid_query_seeded(const GridParams& gp, const Rec* __restrict__ recs, const int* __restrict__ start,
                                 const double* q, double& best, int& bidx, int& visited, int& tie,
-                                const double* __restrict__ cloud) {
+                                const double* __restrict__ cloud, const float* q32 = nullptr) {
     int c[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < D; d++) c[d] = cell_coord<D>(gp, q[d], d);
@@ -400,7 +457,7 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict_
     if (D == 3) range_of(2, rad, z0, z1);
     range_of(1, rad, y0, y1);
     if (z1 - z0 > 2 || y1 - y0 > 2) {
-        grid_ball_scan<D, TIES>(gp, recs, start, q, c, best, bidx, visited, tie, cloud);
+        grid_ball_scan<D, TIES, Rec>(gp, recs, start, q, c, best, bidx, visited, tie, cloud, q32);
         return;
     }
     constexpr int NR = D == 3 ? 9 : 3;
@@ -419,17 +476,18 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const GridRec* __restrict_
         kb[t] = start[row + x0];
         ke[t] = in ? start[row + x1 + 1] : kb[t];
     }
-    grid_scan_rows<D, NR, TIES>(recs, q, kb, ke, best, bidx, visited, tie, cloud);
+    grid_scan_rows<D, NR, TIES, Rec>(recs, q, kb, ke, best, bidx, visited, tie, cloud, q32);
 }
 
 // one query against the grid.  Returns (best d2, lowest index among equal d2); (inf, 0) when no
 // target has a finite distance.
 // (r0, best0, bidx0): the shells below r0 have been visited already, with this result (grid_block_query)
-template <int D, bool TIES = false>
-ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
+template <int D, bool TIES = false, typename Rec = GridRec>
+ICPX_DEV void grid_query(const GridParams& gp, const Rec* __restrict__ recs,
                          const int* __restrict__ start, const double* q, double& best_out,
                          int& idx_out, int& visited, int& tie, const double* __restrict__ cloud, const int r0 = 0,
-                         const double best0 = __builtin_inf(), const int bidx0 = 0x7fffffff) {
+                         const double best0 = __builtin_inf(), const int bidx0 = 0x7fffffff, const float* q32 = nullptr) {
+    const auto* qc = RecTraits<Rec>::query(q, q32);
     double best = best0;
     int bidx = bidx0;
     bool qfin = true;
@@ -462,7 +520,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                 kb[t] = start[row + xlo];
                 ke[t] = in ? start[row + xhi + 1] : kb[t];
             }
-            grid_scan_rows<D, NR, TIES>(recs, q, kb, ke, best, bidx, visited, tie, cloud);
+            grid_scan_rows<D, NR, TIES, Rec>(recs, q, kb, ke, best, bidx, visited, tie, cloud, q32);
             // the stopping test after shell 1 (as at the end of the loop below)
             double lb = __builtin_inf();
             bool all_covered = true;
@@ -487,7 +545,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
         for (int r = r_begin; r <= gp.rmax; r++) {
             if (r >= 2 && best < __builtin_inf()) {
                 // shells 0 and 1 did not settle it: the rest through the ball of the candidate
-                grid_ball_scan<D, TIES>(gp, recs, start, q, c, best, bidx, visited, tie, cloud);
+                grid_ball_scan<D, TIES, Rec>(gp, recs, start, q, c, best, bidx, visited, tie, cloud, q32);
                 break;
             }
             const int zlo = D == 3 ? (c[2] - r > 0 ? c[2] - r : 0) : 0;
@@ -523,7 +581,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                     for (int s = 0; s < nseg; s++) {
                         // 4 records in flight per step: the walk is latency-bound, not bandwidth-bound
                         for (int k0 = seg_b[s]; k0 < seg_e[s]; k0 += 4) {
-                            GridRec rec[4];
+                            Rec rec[4];
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
                                 int k = k0 + u < seg_e[s] ? k0 + u : seg_e[s] - 1;
@@ -531,16 +589,9 @@ ICPX_DEV void grid_query(const GridParams& gp, const GridRec* __restrict__ recs,
                             }
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
-                                double df = rec[u].x - q[0];
-                                double dist = df * df;
-                                df = rec[u].y - q[1];
-                                dist = dist + df * df;
-                                if (D == 3) {
-                                    df = rec[u].z - q[2];
-                                    dist = dist + df * df;
-                                }
+                                const double dist = d2_eval<D>(rec[u].x, rec[u].y, rec[u].z, qc);
                                 const int j = static_cast<int>(rec[u].idx);
-                                const double cc[3] = {rec[u].x, rec[u].y, rec[u].z};
+                                const double cc[3] = {static_cast<double>(rec[u].x), static_cast<double>(rec[u].y), static_cast<double>(rec[u].z)};
                                 nn_take<TIES, D>(k0 + u < seg_e[s], dist, j, cc, cloud, best, bidx, tie);
                             }
                             visited += seg_e[s] - k0 < 4 ? seg_e[s] - k0 : 4;
@@ -615,9 +666,10 @@ __global__ void grid_block_starts_kernel(const uint32_t* __restrict__ keys_sorte
 }
 
 // Workgroup-wide: stages the block's box.  Returns false (uniformly) when it does not fit.  b0 / b1: the box.
-template <int D>
-ICPX_DEV bool grid_block_stage(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start, const int blk,
+template <int D, typename Rec = GridRec>
+ICPX_DEV bool grid_block_stage(const GridParams& gp, const Rec* __restrict__ recs, const int* __restrict__ start, const int blk,
                                char* lds, int (&b0)[3], int (&b1)[3]) {
+    using C = typename RecTraits<Rec>::coord;
     const int tid = threadIdx.x, T = blockDim.x;
     int nt[3];
     grid_tiles(gp, D, nt);
@@ -631,7 +683,7 @@ ICPX_DEV bool grid_block_stage(const GridParams& gp, const GridRec* __restrict__
     b1[2] = D == 3 ? min(2 * tz + 2, gp.g[2] - 1) : 0;
     const int nx = b1[0] - b0[0] + 1, ny = b1[1] - b0[1] + 1, nz = b1[2] - b0[2] + 1;
     const int nrows = ny * nz;
-    double* sx = reinterpret_cast<double*>(lds);
+    C* sx = reinterpret_cast<C*>(lds);
     int* sidx = reinterpret_cast<int*>(sx + 3 * kGridBlkRecs);
     int* slice = sidx + kGridBlkRecs;
     int* rowoff = slice + kGridBlkSlice;
@@ -674,7 +726,7 @@ ICPX_DEV bool grid_block_stage(const GridParams& gp, const GridRec* __restrict__
             const int t = r + step;
             r = (t < nrows && rowoff[t] <= i) ? t : r;
         }
-        const GridRec rec = recs[rowbeg[r] + (i - rowoff[r])];
+        const Rec rec = recs[rowbeg[r] + (i - rowoff[r])];
         sx[i] = rec.x;
         sx[kGridBlkRecs + i] = rec.y;
         if (D == 3) sx[2 * kGridBlkRecs + i] = rec.z;
@@ -685,10 +737,13 @@ ICPX_DEV bool grid_block_stage(const GridParams& gp, const GridRec* __restrict__
 }
 
 // One query of a staged block (staged: grid_block_stage returned true).  Per lane; no barriers.
-template <int D, bool TIES = false>
-ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+template <int D, bool TIES = false, typename Rec = GridRec>
+ICPX_DEV void grid_block_query(const GridParams& gp, const Rec* __restrict__ recs, const int* __restrict__ start,
                                const double* q, const bool staged, const int (&b0)[3], const int (&b1)[3], const char* lds,
-                               double& best_out, int& idx_out, int& visited, int& tie, const double* __restrict__ cloud) {
+                               double& best_out, int& idx_out, int& visited, int& tie, const double* __restrict__ cloud,
+                               const float* q32 = nullptr) {
+    using C = typename RecTraits<Rec>::coord;
+    const auto* qc = RecTraits<Rec>::query(q, q32);
     bool qfin = gp.m > 0;
 #pragma unroll
     for (int d = 0; d < D; d++) qfin = qfin && finite_d(q[d]);
@@ -705,10 +760,10 @@ ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__
         inside = inside && max(c[d] - 1, 0) >= b0[d] && min(c[d] + 1, gp.g[d] - 1) <= b1[d];
     }
     if (!inside) {
-        grid_query<D, TIES>(gp, recs, start, q, best_out, idx_out, visited, tie, cloud);
+        grid_query<D, TIES, Rec>(gp, recs, start, q, best_out, idx_out, visited, tie, cloud, 0, __builtin_inf(), 0x7fffffff, q32);
         return;
     }
-    const double* sx = reinterpret_cast<const double*>(lds);
+    const C* sx = reinterpret_cast<const C*>(lds);
     const int* sidx = reinterpret_cast<const int*>(sx + 3 * kGridBlkRecs);
     const int* slice = sidx + kGridBlkRecs;
     const int nx = b1[0] - b0[0] + 1, ny = b1[1] - b0[1] + 1;
@@ -720,16 +775,10 @@ ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__
             const int rr = (z - b0[2]) * ny + (y - b0[1]);
             const int s = slice[rr * (nx + 1) + xs], e = slice[rr * (nx + 1) + xe];
             for (int k = s; k < e; k++) {
-                double df = sx[k] - q[0];
-                double dist = df * df;
-                df = sx[kGridBlkRecs + k] - q[1];
-                dist = dist + df * df;
-                if (D == 3) {
-                    df = sx[2 * kGridBlkRecs + k] - q[2];
-                    dist = dist + df * df;
-                }
+                const C tx = sx[k], ty = sx[kGridBlkRecs + k], tz = D == 3 ? sx[2 * kGridBlkRecs + k] : C(0);
+                const double dist = d2_eval<D>(tx, ty, tz, qc);
                 const int j = sidx[k];
-                const double cc[3] = {sx[k], sx[kGridBlkRecs + k], D == 3 ? sx[2 * kGridBlkRecs + k] : 0.0};
+                const double cc[3] = {static_cast<double>(tx), static_cast<double>(ty), static_cast<double>(tz)};
                 nn_take<TIES, D>(true, dist, j, cc, cloud, best, bidx, tie);
             }
             visited += e - s;
@@ -758,7 +807,7 @@ ICPX_DEV void grid_block_query(const GridParams& gp, const GridRec* __restrict__
         best_out = best;
         idx_out = bidx == 0x7fffffff ? 0 : bidx;
     } else {
-        grid_query<D, TIES>(gp, recs, start, q, best_out, idx_out, visited, tie, cloud, 2, best, bidx);
+        grid_query<D, TIES, Rec>(gp, recs, start, q, best_out, idx_out, visited, tie, cloud, 2, best, bidx, q32);
     }
 }
 
@@ -768,9 +817,9 @@ ICPX_DEV void kd_append(const int tie, const int64_t i, uint32_t* __restrict__ k
     if (tie) kd_list[atomicAdd(kd_count, 1)] = static_cast<uint32_t>(i);
 }
 
-template <int D, bool TIES = false>
+template <int D, bool TIES = false, typename Rec = GridRec>
 __global__ void __launch_bounds__(256)
-grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec* __restrict__ recs,
+grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const Rec* __restrict__ recs,
                      const int* __restrict__ start, int64_t* __restrict__ idx, double* __restrict__ d2,
                      unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm,
                      const int* __restrict__ qstart, const double* __restrict__ cloud = nullptr,
@@ -779,7 +828,7 @@ grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec*
     const int qs = qstart[blockIdx.x], qe = qstart[blockIdx.x + 1];
     if (qs >= qe) return;  // (uniform)
     int b0[3], b1[3];
-    const bool staged = grid_block_stage<D>(gp, recs, start, blockIdx.x, grid_lds, b0, b1);
+    const bool staged = grid_block_stage<D, Rec>(gp, recs, start, blockIdx.x, grid_lds, b0, b1);
     int visited = 0;
     for (int k = qs + threadIdx.x; k < qe; k += blockDim.x) {
         const int64_t i = perm[k];
@@ -789,7 +838,9 @@ grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec*
         double best;
         int bi;
         int tie = 0;
-        grid_block_query<D, TIES>(gp, recs, start, qq, staged, b0, b1, grid_lds, best, bi, visited, tie, cloud);
+        float q32[3];
+        if (RecTraits<Rec>::f32) query_f32<D>(gp.lo, qq, q32);
+        grid_block_query<D, TIES, Rec>(gp, recs, start, qq, staged, b0, b1, grid_lds, best, bi, visited, tie, cloud, q32);
         if (idx) idx[i] = bi;
         if (d2) d2[i] = best;
         if (TIES) kd_append(tie, i, kd_list, kd_count);
@@ -800,9 +851,9 @@ grid_nn_block_kernel(const double* __restrict__ q, GridParams gp, const GridRec*
     }
 }
 
-template <int D, bool TIES = false>
+template <int D, bool TIES = false, typename Rec = GridRec>
 __global__ void __launch_bounds__(256)
-grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const GridRec* __restrict__ recs,
+grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const Rec* __restrict__ recs,
                const int* __restrict__ start, int64_t* __restrict__ idx, double* __restrict__ d2,
                unsigned long long* __restrict__ visited_total, const uint32_t* __restrict__ perm,
                const double* __restrict__ cloud = nullptr, uint32_t* __restrict__ kd_list = nullptr,
@@ -819,7 +870,9 @@ grid_nn_kernel(const double* __restrict__ q, int64_t n, GridParams gp, const Gri
         double best;
         int bi;
         int tie = 0;
-        grid_query<D, TIES>(gp, recs, start, qq, best, bi, visited, tie, cloud);
+        float q32[3];
+        if (RecTraits<Rec>::f32) query_f32<D>(gp.lo, qq, q32);
+        grid_query<D, TIES, Rec>(gp, recs, start, qq, best, bi, visited, tie, cloud, 0, __builtin_inf(), 0x7fffffff, q32);
         if (idx) idx[i] = bi;
         if (d2) d2[i] = best;
         if (TIES) kd_append(tie, i, kd_list, kd_count);

@@ -44,6 +44,9 @@ int kd_resolve_queries(int dim, const double* d_q, int64_t n, const double* d_t,
 struct GridIndex;
 int grid_create(GridIndex** out);
 void grid_destroy(GridIndex* g);
+// opt-in f32 correspondence mode (ICPX_NN_GRID_F32): the next grid_build writes 16-byte f32 records and the queries
+// evaluate candidates in f32 (icpx_grid.h, GridRec32).  Off by default; set before grid_build.
+void grid_set_f32(GridIndex* g, bool on);
 // d_t: DEVICE pointer, AoS dim x m.  Synchronises the stream once (bounding box read-back).
 // defer: the first round's occupied-cell count is not waited for; call grid_settle before using occupancy or querying
 int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream, bool defer = false);

@@ -52,6 +52,7 @@ struct GridIndex {
     GridParams gp{};
     int dim = 0;
     int ncell = 0;
+    bool f32 = false;  // set before grid_build: `recs` holds GridRec32 (opt-in f32 correspondence mode, icpx_grid.h)
     DevBuf recs, start, cell_id, counts, keys, totals;
     // query order by cell (grid_sort_queries); q_perm_n == 0: none
     DevBuf q_keys, q_keys_out, q_iota, q_perm, q_tmp, q_start;
@@ -271,7 +272,7 @@ __global__ void lg_sd_unpack_kernel(const double* __restrict__ cur_s, const int6
 // transform*a (opt-in ICPX_FLAG_MATCH_TRANSFORMED, not reference behaviour).
 // qstart != null: block-cooperative (icpx_grid.h) — one workgroup per block of tiles, its queries the range
 // [qstart[b], qstart[b + 1]) of the order `perm`; otherwise one query per thread.
-template <int D, int METHOD, int MODE>
+template <int D, int METHOD, int MODE, typename Rec = GridRec>
 // (six waves per SIMD: the 80-register budget costs the per-lane walk nothing and hides more of its memory latency —
 // clustered config-4 converge 6.83 -> 6.55 ms; eight waves spill and lose)
 #ifndef ICPX_LG_NN_WAVES
@@ -279,7 +280,7 @@ template <int D, int METHOD, int MODE>
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPX_LG_NN_WAVES, 8)))
 lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, double* __restrict__ cur,
-             int64_t n, GridParams gp, const GridRec* __restrict__ recs, const int* __restrict__ start,
+             int64_t n, GridParams gp, const Rec* __restrict__ recs, const int* __restrict__ start,
              int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost, uint8_t* __restrict__ sel,
              double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh,
              const double* __restrict__ seed_tgt, const double* __restrict__ cloud, uint32_t* __restrict__ kd_list,
@@ -287,7 +288,9 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
              double* __restrict__ pt_s = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     // the kd-tree methods follow the reference tree's tie rule (icpx_kd.h): flagged queries go on kd_list
-    constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
+    // (not in the opt-in f32 mode, GridRec32: it gives up index parity altogether)
+    constexpr bool F32 = RecTraits<Rec>::f32;
+    constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2 && !F32;
     if (lg_skip(dev, respect_done)) return;
     // the query of point i as the method defines it
     auto query_of = [&](const int64_t i, double (&q)[D]) {
@@ -317,10 +320,13 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
             for (int d = 0; d < D; d++) cur[i * D + d] = q[d];
         }
     };
-    auto publish = [&](const int64_t i, const double best, const int bi, const int tie) {
+    auto publish = [&](const int64_t i, double best, const int bi, const int tie, const double* q = nullptr) {
         nb_idx[i] = bi;
+        double b[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int d = 0; d < D; d++) nb_pt[i * D + d] = cloud[static_cast<int64_t>(bi) * D + d];
+        for (int d = 0; d < D; d++) nb_pt[i * D + d] = b[d] = cloud[static_cast<int64_t>(bi) * D + d];
+        // f32 mode: the search chose the target in f32; its cost is the f64 distance to that target, as everywhere else
+        if (F32 && q != nullptr && gp.m > 0) best = d2_eval<D>(b[0], b[1], b[2], q);
         if (TIES && tie) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(i);
         if (MODE == 2) {
             nb_cost[i] = best;  // trimmed.cpp:101 squaredNorm; selection comes from lg_select_kernel
@@ -350,15 +356,17 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         const int qs = qstart[blockIdx.x], qe = qstart[blockIdx.x + 1];
         if (qs >= qe) return;  // (uniform)
         int b0[3], b1[3];
-        const bool staged = grid_block_stage<D>(gp, recs, start, blockIdx.x, grid_lds, b0, b1);
+        const bool staged = grid_block_stage<D, Rec>(gp, recs, start, blockIdx.x, grid_lds, b0, b1);
         for (int k = qs + threadIdx.x; k < qe; k += blockDim.x) {
             const int64_t i = perm[k];
             double q[D], best;
             int bi;
             query_of(i, q);
             int tie = 0;
-            grid_block_query<D, TIES>(gp, recs, start, q, staged, b0, b1, grid_lds, best, bi, visited, tie, cloud);
-            publish(i, best, bi, tie);
+            float q32[3];
+            if (F32) query_f32<D>(gp.lo, q, q32);
+            grid_block_query<D, TIES, Rec>(gp, recs, start, q, staged, b0, b1, grid_lds, best, bi, visited, tie, cloud, q32);
+            publish(i, best, bi, tie, q);
         }
         return;
     }
@@ -382,6 +390,8 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
 #pragma unroll
             for (int d = 0; d < D; d++) cur_s[k * D + d] = q[d];
         }
+        float q32[3];
+        if (F32) query_f32<D>(gp.lo, q, q32);
         bool searched = false;
         int64_t sidx = -1;
         if (seed_tgt) {
@@ -401,11 +411,11 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
             if (ok) {
                 best = d2s;
                 bi = static_cast<int>(sidx);
-                grid_query_seeded<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
+                grid_query_seeded<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, q32);
                 searched = true;
             }
         }
-        if (!searched) grid_query<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
+        if (!searched) grid_query<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, 0, __builtin_inf(), 0x7fffffff, q32);
         // nb_pt[i] always holds the coordinates of target idx_s[k] (the resolve kernel keeps that too): a query whose
         // neighbour is the one of the previous step — most of them, late in a converge — has nothing to gather or scatter
         if (static_cast<int64_t>(bi) != sidx) {
@@ -425,6 +435,8 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     int bi;
     query_of(i, q);
     int tie = 0;
+    float q32[3];
+    if (F32) query_f32<D>(gp.lo, q, q32);
     if (seed_tgt) {
         // nb_idx holds the neighbour of the previous correspondence step (the target cloud is seed_tgt): a candidate
         // whose ball bounds the search (grid_query_seeded).  Same (d2, index) minimum as the unseeded query.
@@ -443,13 +455,13 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         if (ok) {
             best = d2s;
             bi = static_cast<int>(s);
-            grid_query_seeded<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
-            publish(i, best, bi, tie);
+            grid_query_seeded<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, q32);
+            publish(i, best, bi, tie, q);
             return;
         }
     }
-    grid_query<D, TIES>(gp, recs, start, q, best, bi, visited, tie, cloud);
-    publish(i, best, bi, tie);
+    grid_query<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, 0, __builtin_inf(), 0x7fffffff, q32);
+    publish(i, best, bi, tie, q);
 }
 
 // ---- tiled brute-force correspondence for mid-size clouds --------------------------------------
@@ -1259,6 +1271,8 @@ void grid_destroy(GridIndex* g) {
 constexpr double kGridDegenerate = 48.0;
 bool grid_degenerate(const GridIndex* g) { return g->per_occupied > kGridDegenerate; }
 
+void grid_set_f32(GridIndex* g, bool on) { g->f32 = on; }
+
 int grid_count_rounds(GridIndex* g, hipStream_t stream, int first, bool defer);
 int grid_scan_scatter(GridIndex* g, hipStream_t stream);
 bool grid_wants_finer(GridIndex* g, int occ);
@@ -1419,12 +1433,19 @@ int grid_scan_scatter(GridIndex* g, hipStream_t stream) {
     hipLaunchKernelGGL(grid_scan_local_kernel, dim3(nb), dim3(256), 0, stream, g->counts.as<int>(), g->ncell, g->totals.as<int>(), g->start.as<int>());
     ICPX_HIP(hipGetLastError());
     ICPX_HIP(hipMemsetAsync(g->counts.p, 0, sizeof(int) * (total + 2), stream));  // reuse as cursors
-    if (g->dim == 2)
-        hipLaunchKernelGGL(grid_scatter_kernel<2>, dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
-                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>());
+    if (g->f32) {
+        if (g->dim == 2)
+            hipLaunchKernelGGL((grid_scatter_kernel<2, GridRec32>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
+                               g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec32>(), g->gp);
+        else
+            hipLaunchKernelGGL((grid_scatter_kernel<3, GridRec32>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
+                               g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec32>(), g->gp);
+    } else if (g->dim == 2)
+        hipLaunchKernelGGL((grid_scatter_kernel<2, GridRec>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
+                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>(), GridParams{});
     else
-        hipLaunchKernelGGL(grid_scatter_kernel<3>, dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
-                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>());
+        hipLaunchKernelGGL((grid_scatter_kernel<3, GridRec>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
+                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>(), GridParams{});
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -1498,6 +1519,22 @@ int grid_query_launch(const GridIndex* g, const double* d_q, int64_t n, int64_t*
     const double* cloud = ties ? ties->cloud : nullptr;
     uint32_t* kl = ties ? ties->list : nullptr;
     int* kc = ties ? ties->count : nullptr;
+    if (g->f32) {
+        // opt-in f32 mode (GridRec32): same kernels over the 16-byte records; no kd rule (index parity is given up anyway)
+        if (ties) return fail(ICPX_ERR_UNSUPPORTED, "the f32 grid mode has no kd-tree tie rule");
+        if (perm != nullptr && g->q_blocks > 0 && knobs().grid_coop != 0 && (g->occupied_frac >= 0.5 || knobs().grid_coop == 2)) {
+            auto kern = g->dim == 2 ? grid_nn_block_kernel<2, false, GridRec32> : grid_nn_block_kernel<3, false, GridRec32>;
+            hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(g->q_blocks)), dim3(256), kGridBlkBytes, stream, d_q,
+                               g->gp, g->recs.as<GridRec32>(), g->start.as<int>(), d_idx, d_d2, d_visited, perm, g->q_start.as<int>(),
+                               nullptr, nullptr, nullptr);
+        } else {
+            auto kern = g->dim == 2 ? grid_nn_kernel<2, false, GridRec32> : grid_nn_kernel<3, false, GridRec32>;
+            hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, d_q, n, g->gp,
+                               g->recs.as<GridRec32>(), g->start.as<int>(), d_idx, d_d2, d_visited, perm, nullptr, nullptr, nullptr);
+        }
+        ICPX_HIP(hipGetLastError());
+        return ICPX_OK;
+    }
     // queries in tile order: one workgroup per block of tiles, its cells staged in LDS (icpx_grid.h)
     // — for clouds that fill their grid: with most cells empty (surfaces, clusters) the occupied blocks overflow the
     // staging area and the per-lane walk is faster (clustered config 4: 1.09 vs 1.49 ms)
@@ -2049,8 +2086,8 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
     if (!lg->tile) {
         if (lg->use_bvh) {
             const BvhIndex* bv = lg->bvh;
-            hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), sizeof(float) * 6 * kBvhTopNodes, lg->stream, dev,
-                               respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, GridParams{}, nullptr, nullptr,
+            hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE, GridRec>), dim3(nb), dim3(256), sizeof(float) * 6 * kBvhTopNodes, lg->stream, dev,
+                               respect, lg->src.as<double>(), lg->cur.as<double>(), lg->n, GridParams{}, static_cast<const GridRec*>(nullptr), nullptr,
                                lg->nb_idx.as<int64_t>(), lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance,
                                bv->q_perm_n == lg->n ? bv->q_perm.as<uint32_t>() : nullptr, nullptr, bv->view(), nullptr,
                                lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>());
@@ -2063,7 +2100,28 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
         // moved by more than a cell most queries have left their block's staged cells (config 4 converge: 26.6 vs 19.4 ms)
         const bool blk = perm != nullptr && g->q_blocks > 0 && knobs().grid_coop == 2;
         const bool sd_step = lg->sd && D == 3 && MODE == 0 && !blk && perm != nullptr;
-        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE>), dim3(blk ? static_cast<unsigned>(g->q_blocks) : nb), dim3(256),
+        if (g->f32) {
+            // opt-in f32 mode (3D methods' per-iteration stage only: large_begin refuses the rest)
+            if constexpr (D == 3 && MODE == 0) {
+                hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE, GridRec32>), dim3(blk ? static_cast<unsigned>(g->q_blocks) : nb), dim3(256),
+                                   blk ? kGridBlkBytes : 0, lg->stream, dev, respect,
+                                   lg->src.as<double>(), lg->cur.as<double>(), lg->n, g->gp,
+                                   g->recs.as<GridRec32>(), g->start.as<int>(), lg->nb_idx.as<int64_t>(),
+                                   lg->nb_cost.as<double>(), lg->sel.as<uint8_t>(), lg->prm.max_distance, perm,
+                                   blk ? g->q_start.as<int>() : nullptr, BvhView{},
+                                   (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr,
+                                   lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>(),
+                                   (sd_step ? lg->cur_s.as<double>() : nullptr), (sd_step ? lg->idx_s.as<int64_t>() : nullptr),
+                                   (sd_step ? lg->pt_s.as<double>() : nullptr));
+                ICPX_HIP(hipGetLastError());
+                if (sd_step) lg->sd_dirty = true;
+                lg->nn_seeded = true;
+                return ICPX_OK;
+            } else {
+                return fail(ICPX_ERR_UNSUPPORTED, "nn = grid_f32 serves the 3D methods without flags");
+            }
+        }
+        hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE, GridRec>), dim3(blk ? static_cast<unsigned>(g->q_blocks) : nb), dim3(256),
                            blk ? kGridBlkBytes : 0, lg->stream, dev, respect,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, g->gp,
                            g->recs.as<GridRec>(), g->start.as<int>(), lg->nb_idx.as<int64_t>(),
@@ -2254,7 +2312,11 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     ICPX_HIP(hipMemsetAsync(lg->sel.p, 1, n, lg->stream));
     lg->sorted = false;
     lg->feature = D == 2 && lg->method == ICPX_FEATURE_AWARE;
-    lg->kd_rule = !lg->feature && (D == 3 || lg->method == ICPX_VANILLA);
+    const bool f32 = lg->prm.nn_mode == ICPX_NN_GRID_F32;
+    if (f32 && (D != 3 || lg->feature || lg->prm.flags != 0))
+        return fail(ICPX_ERR_UNSUPPORTED, "nn = grid_f32 serves the 3D methods (vanilla, trimmed) without flags");
+    // (the f32 mode gives up index parity: no kd-tree tie rule there)
+    lg->kd_rule = !lg->feature && (D == 3 || lg->method == ICPX_VANILLA) && !f32;
     lg->kd_ready = false;
     lg->kd_wait = false;
     if (lg->kd_rule) ICPX_TRY(lg->kd_list.reserve(sizeof(uint32_t) * n));
@@ -2298,7 +2360,7 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     lg->sd = false;
     lg->sd_dirty = false;
     lg->tile = lg->feature || lg->prm.nn_mode == ICPX_NN_BRUTE ||
-               (lg->prm.nn_mode != ICPX_NN_GRID && lg->prm.nn_mode != ICPX_NN_BVH &&
+               (lg->prm.nn_mode != ICPX_NN_GRID && lg->prm.nn_mode != ICPX_NN_GRID_F32 && lg->prm.nn_mode != ICPX_NN_BVH &&
                 static_cast<double>(n) * static_cast<double>(m) <= static_cast<double>(kTileMaxWork));
     if (lg->tile) {
         const int64_t min_split = knobs().tile_min.load() > 0 ? knobs().tile_min.load() : kTileMinSplit;  // development knob ICPX_TILE_MIN
@@ -2331,6 +2393,7 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         // (far-apart clusters) and nothing was forced
         lg->use_bvh = lg->prm.nn_mode == ICPX_NN_BVH;
         if (!lg->use_bvh) {
+            grid_set_f32(lg->grid, f32);
             ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
             lg->use_bvh = lg->prm.nn_mode == ICPX_NN_AUTO && grid_degenerate(lg->grid);
         }

@@ -35,7 +35,8 @@ namespace icp {
             else if (nn == "brute") p.nn_mode = ICPX_NN_BRUTE;
             else if (nn == "grid") p.nn_mode = ICPX_NN_GRID;
             else if (nn == "bvh") p.nn_mode = ICPX_NN_BVH;
-            else throw std::invalid_argument("icp::Config nn must be auto, brute, grid or bvh (got \"" + nn + "\")");
+            else if (nn == "grid_f32") p.nn_mode = ICPX_NN_GRID_F32;  // opt-in f32 correspondence mode (not reference arithmetic)
+            else throw std::invalid_argument("icp::Config nn must be auto, brute, grid, bvh or grid_f32 (got \"" + nn + "\")");
             icpx_check(icpx_create(static_cast<int>(Dim), method, &p, &h_));
         }
 

@@ -67,9 +67,18 @@ enum icpx_nn_mode {
     ICPX_NN_AUTO = 0,  /* brute force (LDS tiles, f32 filter + exact f64) up to ~3e4 x 3e4, uniform grid beyond */
     ICPX_NN_BRUTE = 1, /* LDS-tiled brute force                                     */
     ICPX_NN_GRID = 2,  /* exact uniform-grid search                                 */
-    ICPX_NN_BVH = 3    /* exact search through a linear bounding-volume hierarchy (Morton order, implicit
+    ICPX_NN_BVH = 3,   /* exact search through a linear bounding-volume hierarchy (Morton order, implicit
                           binary tree): the stand-in for the reference's kd-tree (kdtree.h:96-154) on clouds
                           that fill their bounding box very unevenly.  Same results as the other modes */
+    ICPX_NN_GRID_F32 = 4 /* OPT-IN, NOT reference arithmetic: the uniform grid with 16-byte f32 records
+                          (coordinates relative to the grid's lower corner) and candidates evaluated in f32.  The
+                          returned target is the nearest up to that rounding — two targets whose distances from the
+                          query differ by less than about 2^-21 of the cloud's extent may swap — so neither index
+                          parity nor the kd-tree tie rule holds.  Everything downstream of the choice (match cost,
+                          Trimmed3d's selection, sums, Kabsch) stays f64 on the original coordinates.  icpx_nn: d2 is
+                          the f32-evaluated squared distance, widened; handles: Vanilla3d / Trimmed3d without flags
+                          (Config nn = "grid_f32"); icpx_nn_kdtree and the 2D methods: ICPX_ERR_UNSUPPORTED.
+                          Clouds whose extent is beyond ~1e18 overflow f32 squares: use the f64 modes */
 };
 
 /* Opt-in corrections of reference quirks (§8 f4).  NOT reference behaviour:
