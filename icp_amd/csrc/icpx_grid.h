@@ -299,11 +299,21 @@ __global__ void __launch_bounds__(256) grid_scan_local_kernel(const int* __restr
 template <int D, typename Rec = GridRec>
 __global__ void grid_scatter_kernel(const double* __restrict__ t, int64_t m, const int* __restrict__ cell_id,
                                     const int* __restrict__ start, int* __restrict__ cursor,
-                                    Rec* __restrict__ recs, const GridParams gp = GridParams{}) {
+                                    Rec* __restrict__ recs, const GridParams gp = GridParams{},
+                                    GridRec32* __restrict__ filt = nullptr) {
     int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= m) return;
     int c = cell_id[j];
     int pos = start[c] + atomicAdd(&cursor[c], 1);
+    if (filt) {
+        // the same record once more as a 16-byte f32 FILTER record (grid_scan_rows_filtered), at the same position
+        GridRec32 f;
+        f.x = static_cast<float>(t[j * D + 0] - gp.lo[0]);
+        f.y = static_cast<float>(t[j * D + 1] - gp.lo[1]);
+        f.z = D == 3 ? static_cast<float>(t[j * D + 2] - gp.lo[2]) : 0.0f;
+        f.idx = static_cast<int>(j);
+        filt[pos] = f;
+    }
     Rec r;
     if constexpr (RecTraits<Rec>::f32) {
         r.x = static_cast<float>(t[j * D + 0] - gp.lo[0]);
@@ -326,12 +336,14 @@ __global__ void grid_scatter_kernel(const double* __restrict__ t, int64_t m, con
 // TIES (all searches of this file): tie |= another, non-coincident target lies within kKdNearUlps of the minimum
 // (icpx_kd.h; cloud = the targets in cloud order).  The stopping tests leave unvisited only what is farther than
 // (1 + 2^-41) times the best, so every tie partner is among the evaluated records.
-template <int D, int NR, bool TIES = false, typename Rec = GridRec>
+template <int D, int NR, bool TIES = false, typename Rec = GridRec, int STEP = 4>
 ICPX_DEV void grid_scan_rows(const Rec* __restrict__ recs, const double* q, const int (&kb)[NR], const int (&ke)[NR],
                              double& best, int& bidx, int& visited, int& tie, const double* __restrict__ cloud,
                              const float* q32 = nullptr) {
     const auto* qc = RecTraits<Rec>::query(q, q32);
-    constexpr int kStep = 4;  // records in flight per lane (8: more registers, fewer waves, no gain — measured)
+    // records in flight per lane (8: more registers, fewer waves, no gain — measured, f64 and f32 records; STEP = 1:
+    // the rarely taken fallbacks of a kernel that must stay small, lg_nn_kernel<..., LEAN>)
+    constexpr int kStep = STEP;
     int pre[NR], off[NR];
     int total = 0;
 #pragma unroll
@@ -361,6 +373,89 @@ ICPX_DEV void grid_scan_rows(const Rec* __restrict__ recs, const double* q, cons
     visited += total;
 }
 
+// grid_scan_rows for a query that HAS a candidate (best finite), through 16-byte f32 FILTER records — same answer, bit
+// for bit, half the bytes and a third of the arithmetic per scanned record.  A record is the target moved by the
+// grid's lower corner and rounded to f32; its f32 distance to the query (moved and rounded the same way) is off by at
+// most E = 2^-21 M in length (M = the larger of the cloud's extent and the query's offset from the corner: three
+// roundings of 2^-24 (ext + M) per axis, times sqrt 3) and by 3 * 2^-24 relative in the squared sum.  So EVERY target
+// whose exact f64 d2 is <= best has an f32 value <= thr = (sqrt(best) + E)^2 (1 + 2^-21), rounded up: records above
+// thr can neither improve the minimum nor tie with it (a tie partner lies within kKdNearUlps of the minimum, far
+// inside the margin).  The others — the answer, near misses, nothing else late in a converge — are re-evaluated
+// from the ORIGINAL cloud with the reference's f64 expression and the (d2, index) / kd tie rules of nn_take, in
+// scan order like grid_scan_rows.  The current best itself is skipped by index (its exact d2 is `best`).
+// Overflowing or non-finite f32 values compare like the f64 ones would (inf passes only an infinite threshold,
+// NaN never passes and could never be taken).  Measured: config-4 converge lg_nn_kernel 144 -> ... us per iteration.
+template <int D, int NR, bool TIES>
+ICPX_DEV void grid_scan_rows_filtered(const GridRec32* __restrict__ filt, const GridParams& gp, const double* q,
+                                      const int (&kb)[NR], const int (&ke)[NR], double& best, int& bidx, int& visited,
+                                      int& tie, const double* __restrict__ cloud) {
+    // (measured and dropped, all bit-identical: survivors parked per lane and evaluated together with their gathers
+    // in flight at once — 9.67 against 9.56 ms for config 4's converge; the winner's coordinates handed to the caller
+    // instead of its gather of cloud[bidx] — six more live registers, 10.6 ms; eight records in flight — 10.9 ms:
+    // the kernel sits at its 80-register budget and every added live value spills)
+    constexpr int kStep = 4;
+    float q32[3];
+    query_f32<D>(gp.lo, q, q32);
+    double M = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; d++) M = dmax(M, dmax(gp.hi[d] - gp.lo[d], dabs(q[d] - gp.lo[d])));
+    const double E = M * 4.76837158203125e-07;  // 2^-21
+    auto thr_of = [&](const double b) -> float {
+        const double s = sqrt_up(b) + E;
+        return static_cast<float>(s * s * 1.000000476837158203125) * 1.0000002384185791f;  // (1 + 2^-21), then (1 + 2^-22): rounded up
+    };
+    float thr = thr_of(best);
+    int pre[NR], off[NR];
+    int total = 0;
+#pragma unroll
+    for (int t = 0; t < NR; t++) {
+        pre[t] = total;
+        off[t] = kb[t] - total;
+        total += ke[t] - kb[t];
+    }
+    for (int r0 = 0; r0 < total; r0 += kStep) {
+        GridRec32 rec[kStep];
+#pragma unroll
+        for (int u = 0; u < kStep; u++) {
+            const int r = r0 + u < total ? r0 + u : total - 1;
+            int o = off[0];
+#pragma unroll
+            for (int t = 1; t < NR; t++) o = r >= pre[t] ? off[t] : o;
+            rec[u] = filt[r + o];
+        }
+        bool pass[kStep], any = false;
+#pragma unroll
+        for (int u = 0; u < kStep; u++) {
+            float df = rec[u].x - q32[0];
+            float v = df * df;
+            df = rec[u].y - q32[1];
+            v = __builtin_fmaf(df, df, v);
+            if (D == 3) {
+                df = rec[u].z - q32[2];
+                v = __builtin_fmaf(df, df, v);
+            }
+            pass[u] = r0 + u < total && v <= thr && rec[u].idx != bidx;
+            any = any || pass[u];
+        }
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < kStep; u++) {
+                if (pass[u]) {
+                    const int j = rec[u].idx;
+                    double cc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int d = 0; d < D; d++) cc[d] = cloud[static_cast<int64_t>(j) * D + d];
+                    const double dist = d2_eval<D>(cc[0], cc[1], cc[2], q);
+                    const double before = best;
+                    nn_take<TIES, D>(true, dist, j, cc, cloud, best, bidx, tie);
+                    if (best < before) thr = thr_of(best);
+                }
+            }
+        }
+    }
+    visited += total;
+}
+
 // Continuation of a query that has a finite candidate (best, bidx) and has not met the shells' stopping test:
 // instead of more shells (whose cell count grows with the cube of the distance — queries outside the target's
 // box, sparse regions), only the rows of cells that the BALL of the current best can reach are visited, and in
@@ -368,7 +463,7 @@ ICPX_DEV void grid_scan_rows(const Rec* __restrict__ recs, const double* q, cons
 // slabs exactly as in the shells' stopping test (same slack), so a row or cell is skipped only when everything in
 // it is strictly farther than the current best; cell ranges use cell_coord, the (monotone) function that placed
 // the targets.  best only shrinks, so everything at most as far as the final best is evaluated.
-template <int D, bool TIES = false, typename Rec = GridRec>
+template <int D, bool TIES = false, typename Rec = GridRec, int STEP = 4>
 ICPX_DEV void grid_ball_scan(const GridParams& gp, const Rec* __restrict__ recs, const int* __restrict__ start,
                              const double* q, const int (&c)[3], double& best, int& bidx, int& visited, int& tie,
                              const double* __restrict__ cloud, const float* q32 = nullptr) {
@@ -406,12 +501,12 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const Rec* __restrict__ recs,
             range_of(0, sqrt_up(best - far2 + best * 9.0949470177292824e-13), x0, x1);  // + 2^-40 best: the subtraction's rounding
             const int row = (z * gp.g[1] + y) * gp.g[0];
             const int kb = start[row + x0], ke = start[row + x1 + 1];
-            for (int k0 = kb; k0 < ke; k0 += 4) {
-                Rec rec[4];
+            for (int k0 = kb; k0 < ke; k0 += STEP) {
+                Rec rec[STEP];
 #pragma unroll
-                for (int u = 0; u < 4; u++) rec[u] = recs[k0 + u < ke ? k0 + u : ke - 1];
+                for (int u = 0; u < STEP; u++) rec[u] = recs[k0 + u < ke ? k0 + u : ke - 1];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < STEP; u++) {
                     const double dist = d2_eval<D>(rec[u].x, rec[u].y, rec[u].z, qc);
                     const int j = static_cast<int>(rec[u].idx);
                     const double cc[3] = {static_cast<double>(rec[u].x), static_cast<double>(rec[u].y), static_cast<double>(rec[u].z)};
@@ -429,10 +524,11 @@ ICPX_DEV void grid_ball_scan(const GridParams& gp, const Rec* __restrict__ recs,
 // tested and bounded exactly as in grid_ball_scan, but all their bounds are fetched before the first record (the
 // walk is a chain of memory latencies).  The candidate itself is among the visited targets, so the result is the
 // (d2, index) minimum over the whole cloud: what grid_query returns.
-template <int D, bool TIES = false, typename Rec = GridRec>
+template <int D, bool TIES = false, typename Rec = GridRec, int STEP = 4>
 ICPX_DEV void grid_query_seeded(const GridParams& gp, const Rec* __restrict__ recs, const int* __restrict__ start,
                                 const double* q, double& best, int& bidx, int& visited, int& tie,
-                                const double* __restrict__ cloud, const float* q32 = nullptr) {
+                                const double* __restrict__ cloud, const float* q32 = nullptr,
+                                const GridRec32* __restrict__ filt = nullptr) {
     int c[3] = {0, 0, 0};
 #pragma unroll
     for (int d = 0; d < D; d++) c[d] = cell_coord<D>(gp, q[d], d);
@@ -457,7 +553,7 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const Rec* __restrict__ re
     if (D == 3) range_of(2, rad, z0, z1);
     range_of(1, rad, y0, y1);
     if (z1 - z0 > 2 || y1 - y0 > 2) {
-        grid_ball_scan<D, TIES, Rec>(gp, recs, start, q, c, best, bidx, visited, tie, cloud, q32);
+        grid_ball_scan<D, TIES, Rec, STEP>(gp, recs, start, q, c, best, bidx, visited, tie, cloud, q32);
         return;
     }
     constexpr int NR = D == 3 ? 9 : 3;
@@ -476,13 +572,20 @@ ICPX_DEV void grid_query_seeded(const GridParams& gp, const Rec* __restrict__ re
         kb[t] = start[row + x0];
         ke[t] = in ? start[row + x1 + 1] : kb[t];
     }
-    grid_scan_rows<D, NR, TIES, Rec>(recs, q, kb, ke, best, bidx, visited, tie, cloud, q32);
+    if constexpr (!RecTraits<Rec>::f32) {
+        // exact search through the f32 filter records (grid_scan_rows_filtered): same answer
+        if (filt != nullptr) {
+            grid_scan_rows_filtered<D, NR, TIES>(filt, gp, q, kb, ke, best, bidx, visited, tie, cloud);
+            return;
+        }
+    }
+    grid_scan_rows<D, NR, TIES, Rec, STEP>(recs, q, kb, ke, best, bidx, visited, tie, cloud, q32);
 }
 
 // one query against the grid.  Returns (best d2, lowest index among equal d2); (inf, 0) when no
 // target has a finite distance.
 // (r0, best0, bidx0): the shells below r0 have been visited already, with this result (grid_block_query)
-template <int D, bool TIES = false, typename Rec = GridRec>
+template <int D, bool TIES = false, typename Rec = GridRec, int STEP = 4>
 ICPX_DEV void grid_query(const GridParams& gp, const Rec* __restrict__ recs,
                          const int* __restrict__ start, const double* q, double& best_out,
                          int& idx_out, int& visited, int& tie, const double* __restrict__ cloud, const int r0 = 0,
@@ -520,7 +623,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const Rec* __restrict__ recs,
                 kb[t] = start[row + xlo];
                 ke[t] = in ? start[row + xhi + 1] : kb[t];
             }
-            grid_scan_rows<D, NR, TIES, Rec>(recs, q, kb, ke, best, bidx, visited, tie, cloud, q32);
+            grid_scan_rows<D, NR, TIES, Rec, STEP>(recs, q, kb, ke, best, bidx, visited, tie, cloud, q32);
             // the stopping test after shell 1 (as at the end of the loop below)
             double lb = __builtin_inf();
             bool all_covered = true;
@@ -545,7 +648,7 @@ ICPX_DEV void grid_query(const GridParams& gp, const Rec* __restrict__ recs,
         for (int r = r_begin; r <= gp.rmax; r++) {
             if (r >= 2 && best < __builtin_inf()) {
                 // shells 0 and 1 did not settle it: the rest through the ball of the candidate
-                grid_ball_scan<D, TIES, Rec>(gp, recs, start, q, c, best, bidx, visited, tie, cloud, q32);
+                grid_ball_scan<D, TIES, Rec, STEP>(gp, recs, start, q, c, best, bidx, visited, tie, cloud, q32);
                 break;
             }
             const int zlo = D == 3 ? (c[2] - r > 0 ? c[2] - r : 0) : 0;
@@ -580,21 +683,21 @@ ICPX_DEV void grid_query(const GridParams& gp, const Rec* __restrict__ recs,
                     }
                     for (int s = 0; s < nseg; s++) {
                         // 4 records in flight per step: the walk is latency-bound, not bandwidth-bound
-                        for (int k0 = seg_b[s]; k0 < seg_e[s]; k0 += 4) {
-                            Rec rec[4];
+                        for (int k0 = seg_b[s]; k0 < seg_e[s]; k0 += STEP) {
+                            Rec rec[STEP];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
+                            for (int u = 0; u < STEP; u++) {
                                 int k = k0 + u < seg_e[s] ? k0 + u : seg_e[s] - 1;
                                 rec[u] = recs[k];
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
+                            for (int u = 0; u < STEP; u++) {
                                 const double dist = d2_eval<D>(rec[u].x, rec[u].y, rec[u].z, qc);
                                 const int j = static_cast<int>(rec[u].idx);
                                 const double cc[3] = {static_cast<double>(rec[u].x), static_cast<double>(rec[u].y), static_cast<double>(rec[u].z)};
                                 nn_take<TIES, D>(k0 + u < seg_e[s], dist, j, cc, cloud, best, bidx, tie);
                             }
-                            visited += seg_e[s] - k0 < 4 ? seg_e[s] - k0 : 4;
+                            visited += seg_e[s] - k0 < STEP ? seg_e[s] - k0 : STEP;
                         }
                     }
                 }

@@ -47,6 +47,8 @@ void grid_destroy(GridIndex* g);
 // opt-in f32 correspondence mode (ICPX_NN_GRID_F32): the next grid_build writes 16-byte f32 records and the queries
 // evaluate candidates in f32 (icpx_grid.h, GridRec32).  Off by default; set before grid_build.
 void grid_set_f32(GridIndex* g, bool on);
+// the next grid_build also writes f32 filter records (exact seeded queries through them: grid_scan_rows_filtered)
+void grid_set_filter(GridIndex* g, bool on);
 // d_t: DEVICE pointer, AoS dim x m.  Synchronises the stream once (bounding box read-back).
 // defer: the first round's occupied-cell count is not waited for; call grid_settle before using occupancy or querying
 int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t stream, bool defer = false);

@@ -53,6 +53,11 @@ struct GridIndex {
     int dim = 0;
     int ncell = 0;
     bool f32 = false;  // set before grid_build: `recs` holds GridRec32 (opt-in f32 correspondence mode, icpx_grid.h)
+    // set before grid_build: the build also writes `filt`, the records once more as 16-byte f32 FILTER records at the
+    // same positions — the seeded queries of a converge scan those and re-evaluate the survivors from the cloud in f64
+    // (grid_scan_rows_filtered: exact, bit-identical)
+    bool want_filt = false;
+    DevBuf filt;
     DevBuf recs, start, cell_id, counts, keys, totals;
     // query order by cell (grid_sort_queries); q_perm_n == 0: none
     DevBuf q_keys, q_keys_out, q_iota, q_perm, q_tmp, q_start;
@@ -285,7 +290,8 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
              double max_distance, const uint32_t* __restrict__ perm, const int* __restrict__ qstart, const BvhView bvh,
              const double* __restrict__ seed_tgt, const double* __restrict__ cloud, uint32_t* __restrict__ kd_list,
              double* __restrict__ nb_pt, double* __restrict__ cur_s = nullptr, int64_t* __restrict__ idx_s = nullptr,
-             double* __restrict__ pt_s = nullptr) {
+             double* __restrict__ pt_s = nullptr, const GridRec32* __restrict__ filt = nullptr) {
+    // filt: f32 filter records of the same grid (seeded queries scan those, exact results: grid_scan_rows_filtered)
     extern __shared__ __attribute__((aligned(16))) char grid_lds[];
     // the kd-tree methods follow the reference tree's tie rule (icpx_kd.h): flagged queries go on kd_list
     // (not in the opt-in f32 mode, GridRec32: it gives up index parity altogether)
@@ -411,7 +417,7 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
             if (ok) {
                 best = d2s;
                 bi = static_cast<int>(sidx);
-                grid_query_seeded<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, q32);
+                grid_query_seeded<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, q32, filt);
                 searched = true;
             }
         }
@@ -455,13 +461,74 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
         if (ok) {
             best = d2s;
             bi = static_cast<int>(s);
-            grid_query_seeded<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, q32);
+            grid_query_seeded<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, q32, filt);
             publish(i, best, bi, tie, q);
             return;
         }
     }
     grid_query<D, TIES, Rec>(gp, recs, start, q, best, bi, visited, tie, cloud, 0, __builtin_inf(), 0x7fffffff, q32);
     publish(i, best, bi, tie, q);
+}
+
+// The seeded sorted-domain step of lg_nn_kernel (3D methods, per-iteration stage, filter records) as a kernel of its
+// own.  Inside lg_nn_kernel that path shares its register budget (80, for six waves per SIMD) with the f64-record
+// searches of the other paths — four 32-byte records in flight — and spills (132 registers); here the hot path is the
+// filtered scan (grid_scan_rows_filtered: 16-byte records, exact re-evaluation of the survivors from the cloud) and
+// the rare fallbacks — balls beyond 3 x 3 rows, points without a usable seed — walk the f64 records ONE at a time.
+// Same operations on the same values as lg_nn_kernel's branch: bit-identical (ICPX_GRID_FILTER=0 keeps that branch).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPX_LG_NN_WAVES, 8)))
+lg_nn_sd_kernel(LargeDev* dev, int respect_done, int64_t n, GridParams gp, const GridRec* __restrict__ recs,
+                const GridRec32* __restrict__ filt, const int* __restrict__ start, const uint32_t* __restrict__ perm,
+                const double* __restrict__ cloud, uint32_t* __restrict__ kd_list, double* __restrict__ nb_pt,
+                double* __restrict__ cur_s, int64_t* __restrict__ idx_s, double* __restrict__ pt_s) {
+    constexpr int D = 3;
+    if (lg_skip(dev, respect_done)) return;
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = perm[k];
+    double q[D], best;
+    int bi, tie = 0, visited = 0;
+    {
+        Xf<D> S;
+#pragma unroll
+        for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
+        XfRows<D> sr = xf_rows<D>(S);
+        double c[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) c[d] = cur_s[k * D + d];
+        xf_apply<D>(sr, c, q);  // c = T * c, vanilla_3d.cpp:91
+#pragma unroll
+        for (int d = 0; d < D; d++) cur_s[k * D + d] = q[d];
+    }
+    const int64_t sidx = idx_s[k];
+    bool ok = gp.m > 0;
+    double df = pt_s[k * D] - q[0];
+    double d2s = df * df;
+#pragma unroll
+    for (int d = 1; d < D; d++) {
+        df = pt_s[k * D + d] - q[d];
+        d2s = d2s + df * df;
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) ok = ok && finite_d(q[d]);
+    ok = ok && d2s < __builtin_inf();
+    if (ok) {
+        best = d2s;
+        bi = static_cast<int>(sidx);
+        grid_query_seeded<D, true, GridRec, 1>(gp, recs, start, q, best, bi, visited, tie, cloud, nullptr, filt);
+    } else {
+        grid_query<D, true, GridRec, 1>(gp, recs, start, q, best, bi, visited, tie, cloud);
+    }
+    if (static_cast<int64_t>(bi) != sidx) {
+        idx_s[k] = bi;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const double v = cloud[static_cast<int64_t>(bi) * D + d];
+            nb_pt[i * D + d] = v;
+            pt_s[k * D + d] = v;
+        }
+    }
+    if (tie) kd_list[atomicAdd(&dev->kd_count, 1)] = static_cast<uint32_t>(k);
 }
 
 // ---- tiled brute-force correspondence for mid-size clouds --------------------------------------
@@ -1258,7 +1325,7 @@ int grid_create(GridIndex** out) {
 
 void grid_destroy(GridIndex* g) {
     if (!g) return;
-    for (DevBuf* b : {&g->recs, &g->start, &g->cell_id, &g->counts, &g->keys, &g->totals, &g->q_keys, &g->q_keys_out,
+    for (DevBuf* b : {&g->filt, &g->recs, &g->start, &g->cell_id, &g->counts, &g->keys, &g->totals, &g->q_keys, &g->q_keys_out,
                       &g->q_iota, &g->q_perm, &g->q_tmp, &g->q_start})
         b->release();
     if (g->occ_host) (void)hipHostFree(g->occ_host);
@@ -1272,6 +1339,7 @@ constexpr double kGridDegenerate = 48.0;
 bool grid_degenerate(const GridIndex* g) { return g->per_occupied > kGridDegenerate; }
 
 void grid_set_f32(GridIndex* g, bool on) { g->f32 = on; }
+void grid_set_filter(GridIndex* g, bool on) { g->want_filt = on; }
 
 int grid_count_rounds(GridIndex* g, hipStream_t stream, int first, bool defer);
 int grid_scan_scatter(GridIndex* g, hipStream_t stream);
@@ -1440,12 +1508,19 @@ int grid_scan_scatter(GridIndex* g, hipStream_t stream) {
         else
             hipLaunchKernelGGL((grid_scatter_kernel<3, GridRec32>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
                                g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec32>(), g->gp);
-    } else if (g->dim == 2)
-        hipLaunchKernelGGL((grid_scatter_kernel<2, GridRec>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
-                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>(), GridParams{});
-    else
-        hipLaunchKernelGGL((grid_scatter_kernel<3, GridRec>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
-                           g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>(), GridParams{});
+    } else {
+        GridRec32* filt = nullptr;
+        if (g->want_filt) {
+            ICPX_TRY(g->filt.reserve(sizeof(GridRec32) * m));
+            filt = g->filt.as<GridRec32>();
+        }
+        if (g->dim == 2)
+            hipLaunchKernelGGL((grid_scatter_kernel<2, GridRec>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
+                               g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>(), g->gp, filt);
+        else
+            hipLaunchKernelGGL((grid_scatter_kernel<3, GridRec>), dim3(mb), dim3(256), 0, stream, g->b.d_t, m, g->cell_id.as<int>(),
+                               g->start.as<int>(), g->counts.as<int>(), g->recs.as<GridRec>(), g->gp, filt);
+    }
     ICPX_HIP(hipGetLastError());
     return ICPX_OK;
 }
@@ -2121,6 +2196,17 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
                 return fail(ICPX_ERR_UNSUPPORTED, "nn = grid_f32 serves the 3D methods without flags");
             }
         }
+        if constexpr (D == 3 && MODE == 0) {
+            // seeded sorted-domain steps through the f32 filter records: the lean kernel (same results)
+            if (sd_step && lg->nn_seeded && knobs().grid_seed != 0 && g->want_filt && g->filt.p != nullptr) {
+                hipLaunchKernelGGL(lg_nn_sd_kernel, dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n, g->gp, g->recs.as<GridRec>(),
+                                   g->filt.as<GridRec32>(), g->start.as<int>(), perm, lg->dst.as<double>(), lg->kd_list.as<uint32_t>(),
+                                   lg->nb_pt.as<double>(), lg->cur_s.as<double>(), lg->idx_s.as<int64_t>(), lg->pt_s.as<double>());
+                ICPX_HIP(hipGetLastError());
+                lg->sd_dirty = true;
+                return ICPX_OK;
+            }
+        }
         hipLaunchKernelGGL((lg_nn_kernel<D, METHOD, MODE, GridRec>), dim3(blk ? static_cast<unsigned>(g->q_blocks) : nb), dim3(256),
                            blk ? kGridBlkBytes : 0, lg->stream, dev, respect,
                            lg->src.as<double>(), lg->cur.as<double>(), lg->n, g->gp,
@@ -2130,7 +2216,8 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
                            (!blk && lg->nn_seeded && knobs().grid_seed != 0) ? lg->dst.as<double>() : nullptr,
                            lg->dst.as<double>(), lg->kd_list.as<uint32_t>(), lg->nb_pt.as<double>(),
                            (sd_step ? lg->cur_s.as<double>() : nullptr), (sd_step ? lg->idx_s.as<int64_t>() : nullptr),
-                           (sd_step ? lg->pt_s.as<double>() : nullptr));
+                           (sd_step ? lg->pt_s.as<double>() : nullptr),
+                           (g->want_filt && g->filt.p != nullptr && D == 3 && MODE == 0) ? g->filt.as<GridRec32>() : nullptr);
         ICPX_HIP(hipGetLastError());
         if (sd_step) lg->sd_dirty = true;
         lg->nn_seeded = true;  // nb_idx (idx_s) now holds this step's neighbours
@@ -2394,6 +2481,8 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         lg->use_bvh = lg->prm.nn_mode == ICPX_NN_BVH;
         if (!lg->use_bvh) {
             grid_set_f32(lg->grid, f32);
+            // f32 filter records beside the f64 ones for the 3D methods' seeded per-iteration queries (ICPX_GRID_FILTER=0: none)
+            grid_set_filter(lg->grid, D == 3 && !f32 && !(lg->prm.flags & ICPX_FLAG_FILL_MATCHES) && knobs().grid_filter != 0);
             ICPX_TRY(grid_build(lg->grid, D, lg->dst.as<double>(), m, lg->stream));
             lg->use_bvh = lg->prm.nn_mode == ICPX_NN_AUTO && grid_degenerate(lg->grid);
         }

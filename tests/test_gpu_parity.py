@@ -1093,7 +1093,8 @@ def test_grid_seeded_query_is_bit_identical(icp, ob, knob):
     must give the same converge bit for bit — transforms, cost, every neighbour and distance — on uniform and
     clustered clouds, a lattice (every distance tied many times, the seed is one of the tied targets), sources far
     outside the targets' box (large balls: the general ball scan), non-finite points, 2D trimmed; and the oracle's
-    result at a size it covers."""
+    result at a size it covers.  The 3D methods' seeded query scans 16-byte f32 FILTER records and re-evaluates the
+    survivors from the cloud in f64 (grid_scan_rows_filtered; ICPX_GRID_FILTER=0: the f64 records) — also bit for bit."""
     from icp_amd import synth
     rng = np.random.default_rng(31)
     cases = []
@@ -1112,11 +1113,17 @@ def test_grid_seeded_query_is_bit_identical(icp, ob, knob):
     cases.append(("nonfinite-targets", 3, "vanilla", rng.uniform(-1, 1, (8_000, 3)), bad_t, False))
     s2, t2, _, _ = synth.config5_pairs([14_000], 2, 8_000)
     cases.append(("2d", 2, "trimmed", s2[:6_000], t2[:8_000], True))
+    # far from the origin, and a cloud of tiny extent there: the filter records are relative to the grid's corner
+    so, to, _, _ = synth.config4(40_000)
+    cases.append(("offset", 3, "vanilla", so + 7.0e5, to + 7.0e5, False))
+    cases.append(("offset-tiny", 3, "trimmed", so * 1e-6 + 3.0e3, to * 1e-6 + 3.0e3, False))
     crit = dict(max_iterations=7, transform_tol=(1e-9, 1e-9))
     for name, dim, method, s, t, oracle in cases:
         out = []
-        for env in ("1", "0"):
+        # seeded through the f32 filter records (default), unseeded (f64 records only), seeded on the f64 records
+        for env, filt in (("1", "1"), ("0", "1"), ("1", "0")):
             knob.set("ICPX_GRID_SEED", env)
+            knob.set("ICPX_GRID_FILTER", filt)
             cfg = icp.Config()
             cfg.set("nn", "grid")
             cfg.set("max_distance", 0.35)
@@ -1125,10 +1132,12 @@ def test_grid_seeded_query_is_bit_identical(icp, ob, knob):
             nb = d.icp_.debug_neighbors() if dim == 3 else d.icp_.get_matches_arrays()
             out.append((r.iteration_count, r.transform.copy(), r.cost, [np.array(u) for u in nb]))
         knob.reset("ICPX_GRID_SEED")
-        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]), name
-        assert out[0][2] == out[1][2] or (np.isnan(out[0][2]) and np.isnan(out[1][2])), name
-        for u, v in zip(out[0][3], out[1][3]):
-            assert np.array_equal(u, v, equal_nan=True), name
+        knob.reset("ICPX_GRID_FILTER")
+        for other in (out[1], out[2]):
+            assert out[0][0] == other[0] and np.array_equal(out[0][1], other[1]), name
+            assert out[0][2] == other[2] or (np.isnan(out[0][2]) and np.isnan(other[2])), name
+            for u, v in zip(out[0][3], other[3]):
+                assert np.array_equal(u, v, equal_nan=True), name
         if oracle:
             ro = dev_oracle(ob, dim, method, max_distance=0.35).converge(s, t, None, ob.make_criteria(**crit))
             assert out[0][0] == ro.iteration_count and np.array_equal(out[0][1], ro.transform) and out[0][2] == ro.cost, name
