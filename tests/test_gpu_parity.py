@@ -1200,3 +1200,34 @@ def test_grid_build_deferred_occupancy_transitions(icp, queen):
         ig, dg = icp.nearest_neighbors(q, t, icp.NN_GRID)
         ib, db = icp.nearest_neighbors(q, t, icp.NN_BRUTE)
         assert np.array_equal(ig, ib) and np.array_equal(dg, db)
+
+
+def test_polled_done_flag_equals_copied_flag_across_reuse(icp, queen, knob):
+    """Multi-kernel converge: the done flag / iteration count polled from pinned host memory (ICPX_POLL_DONE=1, the
+    default) against the copy + stream synchronisation per chunk (ICPX_POLL_DONE=0) — same state, bit for bit, also
+    when ONE handle is reused: converge, stepwise begin / iterate (whose kernels must not publish into the polled
+    flags of a finished converge), converge again."""
+    from icp_amd import synth
+    src, tgt, _, _ = synth.config4(50_000)
+    cases = [("queen", queen[0], queen[1], dict(max_iterations=100, transform_tol=(1e-4, 1e-4))),
+             ("grid", src, tgt, dict(max_iterations=9, transform_tol=(1e-9, 1e-9)))]
+    for name, a, b, crit in cases:
+        out = []
+        for env in ("1", "0"):
+            knob.set("ICPX_POLL_DONE", env)
+            d = driver(icp, icp.ICP3, "vanilla", crit)
+            r1 = d.converge(a, b)
+            x = d.icp_
+            x.begin(a, b, np.eye(4))
+            for _ in range(3):
+                x.iterate()
+            mid = x.current_transform().copy()
+            r2 = d.converge(a, b)
+            r3 = d.converge(a[: len(a) // 2], b)
+            out.append((r1, mid, r2, r3))
+        knob.reset("ICPX_POLL_DONE")
+        (p1, pm, p2, p3), (c1, cm, c2, c3) = out
+        assert p1.iteration_count == p2.iteration_count == c1.iteration_count == c2.iteration_count, name
+        assert np.array_equal(p1.transform, p2.transform) and np.array_equal(p1.transform, c1.transform), name
+        assert np.array_equal(c1.transform, c2.transform) and np.array_equal(pm, cm), name
+        assert p3.iteration_count == c3.iteration_count and np.array_equal(p3.transform, c3.transform), name
