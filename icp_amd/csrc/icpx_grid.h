@@ -115,6 +115,7 @@ __global__ void grid_bbox_kernel(const double* __restrict__ t, int64_t m, unsign
         mn[d] = ~0ULL;
         mx[d] = 0ULL;
     }
+#pragma unroll 4
     for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < m;
          j += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         double p[D];

@@ -75,6 +75,7 @@ struct GridIndex {
     } b;
     bool refined_last = false;    // the last build needed a finer round: the next one does not defer (it would build twice)
     int* occ_host = nullptr;      // pinned
+    unsigned long long* keys_host = nullptr;  // pinned: the bounding box keys' read-back (a pageable destination is staged by the runtime)
     hipEvent_t occ_ev = nullptr;
     bool occ_pending = false;
 };
@@ -1329,6 +1330,7 @@ void grid_destroy(GridIndex* g) {
                       &g->q_iota, &g->q_perm, &g->q_tmp, &g->q_start})
         b->release();
     if (g->occ_host) (void)hipHostFree(g->occ_host);
+    if (g->keys_host) (void)hipHostFree(g->keys_host);
     if (g->occ_ev) (void)hipEventDestroy(g->occ_ev);
     delete g;
 }
@@ -1367,14 +1369,17 @@ int grid_build(GridIndex* g, int dim, const double* d_t, int64_t m, hipStream_t 
     ICPX_TRY(g->keys.reserve(sizeof(unsigned long long) * 6));
     unsigned long long init[6] = {~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
     ICPX_HIP(hipMemcpyAsync(g->keys.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    int blocks = static_cast<int>(std::min<int64_t>((m + 255) / 256, 512));
+    // (few, large workgroups: the kernel ends in six 64-bit atomics per workgroup on the same six words, and those
+    // serialise — 512 workgroups: 20 us for a million points, 2048: 52 us)
+    int blocks = static_cast<int>(std::min<int64_t>((m + 1023) / 1024, 128));
     if (dim == 2)
-        hipLaunchKernelGGL(grid_bbox_kernel<2>, dim3(blocks), dim3(256), 0, stream, d_t, m, g->keys.as<unsigned long long>());
+        hipLaunchKernelGGL(grid_bbox_kernel<2>, dim3(blocks), dim3(1024), 0, stream, d_t, m, g->keys.as<unsigned long long>());
     else
-        hipLaunchKernelGGL(grid_bbox_kernel<3>, dim3(blocks), dim3(256), 0, stream, d_t, m, g->keys.as<unsigned long long>());
+        hipLaunchKernelGGL(grid_bbox_kernel<3>, dim3(blocks), dim3(1024), 0, stream, d_t, m, g->keys.as<unsigned long long>());
     ICPX_HIP(hipGetLastError());
-    unsigned long long keys[6];
-    ICPX_HIP(hipMemcpyAsync(keys, g->keys.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
+    if (!g->keys_host) ICPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->keys_host), sizeof(unsigned long long) * 6, hipHostMallocDefault));
+    unsigned long long* keys = g->keys_host;
+    ICPX_HIP(hipMemcpyAsync(keys, g->keys.p, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, stream));
     ICPX_HIP(hipStreamSynchronize(stream));
     // 2. cell size: about 2 targets per cell over the non-degenerate axes
     GridIndex::Build& bs = g->b;
@@ -1456,7 +1461,8 @@ int grid_count_rounds(GridIndex* g, hipStream_t stream, int first, bool defer) {
         g->occupied_frac = 0.0;
         g->per_occupied = static_cast<double>(m);  // (all targets in one point: one cell)
         if (bs.nz == 0) break;
-        hipLaunchKernelGGL(grid_occupied_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 1024))), dim3(256), 0,
+        // (one atomic per workgroup on one word: few workgroups)
+        hipLaunchKernelGGL(grid_occupied_kernel, dim3(static_cast<unsigned>(std::min<int64_t>((total + 4095) / 4096, 128))), dim3(256), 0,
                            stream, g->counts.as<int>(), static_cast<int>(total), d_occ);
         ICPX_HIP(hipGetLastError());
         if (defer && refine == 0) {
@@ -1736,11 +1742,11 @@ int bvh_build(BvhIndex* b, int dim, const double* d_t, int64_t m, hipStream_t st
     ICPX_TRY(b->bbox.reserve(sizeof(unsigned long long) * 6));
     unsigned long long init[6] = {~0ULL, ~0ULL, ~0ULL, 0, 0, 0};
     ICPX_HIP(hipMemcpyAsync(b->bbox.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    const int blocks = static_cast<int>(std::min<int64_t>((m + 255) / 256, 512));
+    const int blocks = static_cast<int>(std::min<int64_t>((m + 1023) / 1024, 128));  // (as grid_build)
     if (dim == 2)
-        hipLaunchKernelGGL(grid_bbox_kernel<2>, dim3(blocks), dim3(256), 0, stream, d_t, m, b->bbox.as<unsigned long long>());
+        hipLaunchKernelGGL(grid_bbox_kernel<2>, dim3(blocks), dim3(1024), 0, stream, d_t, m, b->bbox.as<unsigned long long>());
     else
-        hipLaunchKernelGGL(grid_bbox_kernel<3>, dim3(blocks), dim3(256), 0, stream, d_t, m, b->bbox.as<unsigned long long>());
+        hipLaunchKernelGGL(grid_bbox_kernel<3>, dim3(blocks), dim3(1024), 0, stream, d_t, m, b->bbox.as<unsigned long long>());
     ICPX_HIP(hipGetLastError());
     unsigned long long keys[6];
     ICPX_HIP(hipMemcpyAsync(keys, b->bbox.p, sizeof(keys), hipMemcpyDeviceToHost, stream));
