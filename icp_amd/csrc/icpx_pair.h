@@ -1348,10 +1348,13 @@ __global__ void __launch_bounds__(TMAX, pair_min_waves(D, QPT, TMAX, PRUNE)) pai
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         pick = (c << 1) | ((w & 3) == 0 ? 1 : 0);  // bit 0: fresh -> run setup
                     }
-                } else if (__hip_atomic_load(pb.sched_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P) {
-                    pick = -1;  // everything finished
                 } else {
-                    __builtin_amdgcn_s_sleep(64);
+                    // Nothing fresh or ready: every unfinished pair is running in some workgroup, and that workgroup
+                    // looks again right after it releases the pair (it finds it, or whatever else is ready then) — so
+                    // this one is not needed any more.  It used to poll until the whole batch was done: a 3D workgroup
+                    // owns its compute unit, and whatever waited on another stream (the 2D take-over launch of a bench
+                    // step, the next batch) could not start before the last pair had finished.
+                    pick = -1;
                 }
                 s_pick = pick;
             }
