@@ -506,8 +506,9 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
                          "roofline": {"bound": "hbm", "achieved": it_bytes / it_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                                       "frac": it_bytes / it_s / 1e9 / 8000.0,
                                       "from_profile": newest_profile("_c4_converge_kernel_stats.csv"),
-                                      "note": "per iteration: lg_nn_kernel (seeded grid walk in the sorted domain, a chain of "
-                                              "dependent L2 round trips) ~3/4 of the time, the two sum kernels the rest"}}
+                                      "note": "per iteration: lg_nn_sd_kernel (seeded grid walk in the sorted domain through f32 filter "
+                                              "records with exact f64 refinement, a chain of dependent L2 round trips) ~2/3 of the "
+                                              "time, the two sum kernels the rest"}}
     # configs 2 and 3 (one pair each): the correspondence work of the path is brute force in the SURVEY 8(d) model,
     # 8 flops per (query, target) and correspondence step, against the f64 FMA peak — a latency figure, not a
     # throughput one: one scan-sized pair occupies one compute unit of 256
