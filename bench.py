@@ -358,9 +358,9 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
     drv = icp_amd.ICPDriver(icp_amd.ICP2.from_method("trimmed", device=local_rank))
     drv.set_max_iterations(50)
     drv.set_transform_tolerance(0.1 * np.pi / 180, 0.01)
-    # (ten untimed calls first: after the idle moment between two measurements the GPU needs a few milliseconds of work
-    # to reach its clocks — the first calls of a series are 20 % slower than the steady state, tools/queen_variance.py)
-    for _ in range(10):
+    # (forty untimed calls first: after the idle moment between two measurements the GPU needs some ten milliseconds of
+    # work to reach its clocks — the first calls of a series are 20 % slower than the steady state, tools/queen_variance.py)
+    for _ in range(40):
         r = drv.converge(a, b)
     t0 = time.perf_counter()
     for _ in range(20):
@@ -376,7 +376,7 @@ def extras(torch, icp_amd, synth, dev, local_rank, stream):
     drv3 = icp_amd.ICPDriver(icp_amd.ICP3.from_method("vanilla", device=local_rank))
     drv3.set_max_iterations(100)
     drv3.set_transform_tolerance(1e-4, 1e-4)
-    for _ in range(10):
+    for _ in range(40):
         r = drv3.converge(qt, q)
     t0 = time.perf_counter()
     for _ in range(20):
