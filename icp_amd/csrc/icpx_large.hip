@@ -112,9 +112,11 @@ struct LargeDev {
     int with_cost;    // the matches carry a cost that ICP::calculate_cost sums (2D; 3D with ICPX_FLAG_FILL_MATCHES)
     int update_cost;  // that cost changes in every iterate (not for reference 2D vanilla, Q1)
     // kd-tree tie rule (icpx_kd.h): the correspondence kernels append the queries that have a tie partner
-    int kd_count;     // entries of the list (cleared by the kernel that ends an iteration)
+    // (the four words every per-iteration kernel tests first sit in ONE aligned 16-byte word: lg_head fetches them with one load)
+    alignas(16) int kd_count;  // entries of the list (cleared by the kernel that ends an iteration)
     int kd_ready;     // the target's tree is on the device: kd_resolve_kernel follows every correspondence step
     int kd_stall;     // flagged queries but no tree yet: every kernel returns at once until the host has built it
+    int done_m;       // mirror of st.done (written wherever st.done is)
     int tick1, tick2; // workgroups of lg_sum1 / lg_sum2 that have written their partials (the last one finishes the sums)
     int _pad2;
 };
@@ -124,6 +126,34 @@ ICPX_DEV bool lg_skip(const LargeDev* dev, int respect_done) { return (respect_d
 // ... and the first of them (lg_sum1) turns "flagged queries and no tree" into the stall, telling the host
 ICPX_DEV bool lg_kd_gate(LargeDev* dev, int* hflags) {
     if (dev->kd_count == 0 || dev->kd_ready != 0) return false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dev->kd_stall = 1;
+        if (hflags) __hip_atomic_store(&hflags[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return true;
+}
+
+// The head of a per-iteration kernel.  `lg_skip(dev) -> return; lg_kd_gate(dev) -> return; transform ...` compiled to
+// a chain of loads with a wait and a branch behind each — five or six dependent round trips to words the previous
+// kernel has just written (they come from memory: another XCD's L2), 4 - 6 us of an 11 us kernel.  The four flags are
+// one 16-byte word, fetched once; what else the kernel needs from LargeDev is loaded before the first branch.
+struct LgHead {
+    int kd_count, kd_ready, kd_stall, done;
+};
+ICPX_DEV LgHead lg_head(const LargeDev* dev) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 w = *reinterpret_cast<const i32x4*>(&dev->kd_count);
+    LgHead h;
+    h.kd_count = w[0];
+    h.kd_ready = w[1];
+    h.kd_stall = w[2];
+    h.done = w[3];
+    return h;
+}
+ICPX_DEV bool lg_skip(const LgHead& h, int respect_done) { return (respect_done && h.done) || h.kd_stall != 0; }
+// (lg_kd_gate on the fetched words)
+ICPX_DEV bool lg_kd_gate(const LgHead& h, LargeDev* dev, int* hflags) {
+    if (h.kd_count == 0 || h.kd_ready != 0) return false;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         dev->kd_stall = 1;
         if (hflags) __hip_atomic_store(&hflags[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -204,6 +234,7 @@ __global__ void lg_init_kernel(LargeDev* dev, const double* guess, int with_cost
     dev->st.iteration_count = 0;
     dev->st.have_last = 0;
     dev->st.done = 0;
+    dev->done_m = 0;
     dev->st.cost = 0.0;
     dev->st.last_cost = 0.0;
     dev->st.start_clock = wall_clock64();
@@ -483,16 +514,17 @@ lg_nn_sd_kernel(LargeDev* dev, int respect_done, int64_t n, GridParams gp, const
                 const double* __restrict__ cloud, uint32_t* __restrict__ kd_list, double* __restrict__ nb_pt,
                 double* __restrict__ cur_s, int64_t* __restrict__ idx_s, double* __restrict__ pt_s) {
     constexpr int D = 3;
-    if (lg_skip(dev, respect_done)) return;
+    const LgHead head = lg_head(dev);
+    Xf<D> S;
+#pragma unroll
+    for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
+    if (lg_skip(head, respect_done)) return;
     const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int64_t i = perm[k];
     double q[D], best;
     int bi, tie = 0, visited = 0;
     {
-        Xf<D> S;
-#pragma unroll
-        for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
         XfRows<D> sr = xf_rows<D>(S);
         double c[D];
 #pragma unroll
@@ -583,7 +615,12 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
                   int64_t n, const double* __restrict__ dst, int64_t m, int split_len, int scap,
                   const int64_t* __restrict__ nb_idx, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
     extern __shared__ __attribute__((aligned(16))) double tile_lds[];
-    if (lg_skip(dev, respect_done)) return;
+    const LgHead head = lg_head(dev);
+    const int head_nn_valid = dev->nn_valid;
+    Xf<D> head_xf;
+#pragma unroll
+    for (int e = 0; e < (D + 1) * (D + 1); e++) head_xf.m[e] = MODE == 0 ? dev->step[e] : dev->st.transform[e];
+    if (lg_skip(head, respect_done)) return;
     const int tid = threadIdx.x;
     const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
     const int mt = static_cast<int>(m - t0 < split_len ? m - t0 : split_len);
@@ -609,15 +646,12 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     int bidx[QPT];
     int64_t seed[QPT];
     const int64_t qbase = static_cast<int64_t>(blockIdx.x) * (kTileThreads * QPT);
-    const bool seeded = dev->nn_valid != 0;
+    const bool seeded = head_nn_valid != 0;
     XfRows<D> xr;
     if (MODE == 2 || MODE == 3 || MODE == 0) {
         // MODE 0: c = T * c with the step the previous iteration produced (identity after begin), vanilla_3d.cpp:91 — every
         // split's workgroup computes it from the unstepped cloud (lg_sum1 writes the stepped one behind this kernel)
-        Xf<D> X;
-#pragma unroll
-        for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = MODE == 0 ? dev->step[e] : dev->st.transform[e];
-        xr = xf_rows<D>(X);
+        xr = xf_rows<D>(head_xf);
     }
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
@@ -677,13 +711,15 @@ lg_tile_merge_kernel(LargeDev* dev, int respect_done, int64_t n, int splits, con
                      const int32_t* __restrict__ part_idx, int64_t* __restrict__ nb_idx, double* __restrict__ nb_cost,
                      uint8_t* __restrict__ sel, double max_distance, const double* __restrict__ cloud,
                      uint32_t* __restrict__ kd_list, double* __restrict__ nb_pt) {
-    if (lg_skip(dev, respect_done)) return;
+    const LgHead head = lg_head(dev);
     constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // (the first split's result is fetched beside the head)
+    double best = i < n ? part_d2[i] : 0.0;
+    int32_t bi = i < n ? part_idx[i] : 0;
+    if (lg_skip(head, respect_done)) return;
     if (i == 0) dev->nn_valid = 1;
     if (i >= n) return;
-    double best = part_d2[i];
-    int32_t bi = part_idx[i];
     bool tie = bi < 0;
     bi &= 0x7fffffff;
     // (the partial results of eight splits are fetched together, then merged in split order: one split per trip of
@@ -1113,22 +1149,22 @@ lg_sum1_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
     __shared__ double gs[(2 * D + 1) * 64];
     __shared__ int wcnt[kBlk / 64];
     __shared__ int s_last;
-    if (lg_skip(dev, respect_done)) return;
-    if (lg_kd_gate(dev, hflags)) return;  // flagged queries of the kd rule and no tree on the device yet: stall
-    Xf<D> X;
+    const LgHead head = lg_head(dev);
+    const int head_with_cost = dev->with_cost;
+    Xf<D> X, head_step;
 #pragma unroll
-    for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
+    for (int e = 0; e < (D + 1) * (D + 1); e++) {
+        X.m[e] = dev->st.transform[e];
+        head_step.m[e] = D == 3 ? dev->step[e] : 0.0;
+    }
+    if (lg_skip(head, respect_done)) return;
+    if (lg_kd_gate(head, dev, hflags)) return;  // flagged queries of the kd rule and no tree on the device yet: stall
     XfRows<D> xr = xf_rows<D>(X);
-    const bool with_cost = dev->with_cost != 0;
+    const bool with_cost = head_with_cost != 0;
     // sorted domain (LargeIcp::sd, 3D): the correspondence kernel stepped its own copy of the cloud; the cloud in point
     // order takes the same step here (c = T * c, vanilla_3d.cpp:91), and the selection comes from the two points
     XfRows<D> sr;
-    if (D == 3 && sd_step) {
-        Xf<D> S;
-#pragma unroll
-        for (int e = 0; e < (D + 1) * (D + 1); e++) S.m[e] = dev->step[e];
-        sr = xf_rows<D>(S);
-    }
+    if (D == 3 && sd_step) sr = xf_rows<D>(head_step);
     // the point (as the sums take it) and whether its match is selected
     auto point_of = [&](int64_t i, double (&c)[D], double (&b)[D]) -> bool {
             double p[D];
@@ -1203,17 +1239,18 @@ lg_sum2_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, 
     const bool sd = (sd_flags & 2) != 0;
     __shared__ double gs[D * D * 64];
     __shared__ int s_last;
-    if (lg_skip(dev, respect_done)) return;
+    const LgHead head = lg_head(dev);
     Xf<D> X;
 #pragma unroll
     for (int e = 0; e < (D + 1) * (D + 1); e++) X.m[e] = dev->st.transform[e];
-    XfRows<D> xr = xf_rows<D>(X);
     double ca[D], cb[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         ca[d] = dev->ca[d];
         cb[d] = dev->cb[d];
     }
+    if (lg_skip(head, respect_done)) return;
+    XfRows<D> xr = xf_rows<D>(X);
     auto terms = [&](int64_t i, double (&v)[D * D]) {
             double p[D], c[D], b[D];
             if (D == 2) {
@@ -1266,6 +1303,7 @@ __global__ void lg_setup_finish_kernel(LargeDev* dev, int64_t n, int check, icpx
         double el = host_elapsed_s + static_cast<double>(wall_clock64() - dev->st.start_clock) * clock_to_s;
         if (should_terminate<D>(crit, dev->st, el)) {
             dev->st.done = 1;
+            dev->done_m = 1;
         } else {
             for (int e = 0; e < 16; e++) dev->st.last_transform[e] = dev->st.transform[e];
             dev->st.last_cost = dev->st.cost;
@@ -1307,6 +1345,7 @@ ICPX_DEV void fin2_body(LargeDev* dev, const double* __restrict__ part, int nblk
             double el = host_elapsed_s + static_cast<double>(wall_clock64() - dev->st.start_clock) * clock_to_s;
             if (should_terminate<D>(crit, dev->st, el)) {
                 dev->st.done = 1;
+                dev->done_m = 1;
             } else {
                 for (int e = 0; e < 16; e++) dev->st.last_transform[e] = dev->st.transform[e];
                 dev->st.last_cost = dev->st.cost;
