@@ -121,18 +121,6 @@ struct LargeDev {
     int _pad2;
 };
 
-// every kernel of an iteration behind the correspondence stage begins with this
-ICPX_DEV bool lg_skip(const LargeDev* dev, int respect_done) { return (respect_done && dev->st.done) || dev->kd_stall != 0; }
-// ... and the first of them (lg_sum1) turns "flagged queries and no tree" into the stall, telling the host
-ICPX_DEV bool lg_kd_gate(LargeDev* dev, int* hflags) {
-    if (dev->kd_count == 0 || dev->kd_ready != 0) return false;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        dev->kd_stall = 1;
-        if (hflags) __hip_atomic_store(&hflags[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return true;
-}
-
 // The head of a per-iteration kernel.  `lg_skip(dev) -> return; lg_kd_gate(dev) -> return; transform ...` compiled to
 // a chain of loads with a wait and a branch behind each — five or six dependent round trips to words the previous
 // kernel has just written (they come from memory: another XCD's L2), 4 - 6 us of an 11 us kernel.  The four flags are
@@ -150,8 +138,9 @@ ICPX_DEV LgHead lg_head(const LargeDev* dev) {
     h.done = w[3];
     return h;
 }
+// every kernel of an iteration behind the correspondence stage begins with this
 ICPX_DEV bool lg_skip(const LgHead& h, int respect_done) { return (respect_done && h.done) || h.kd_stall != 0; }
-// (lg_kd_gate on the fetched words)
+// ... and the first of them (lg_sum1) turns "flagged queries and no tree" into the stall, telling the host
 ICPX_DEV bool lg_kd_gate(const LgHead& h, LargeDev* dev, int* hflags) {
     if (h.kd_count == 0 || h.kd_ready != 0) return false;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -329,7 +318,7 @@ lg_nn_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src, do
     // (not in the opt-in f32 mode, GridRec32: it gives up index parity altogether)
     constexpr bool F32 = RecTraits<Rec>::f32;
     constexpr bool TIES = (D == 3 || METHOD == ICPX_VANILLA) && MODE != 2 && !F32;
-    if (lg_skip(dev, respect_done)) return;
+    if (lg_skip(lg_head(dev), respect_done)) return;
     // the query of point i as the method defines it
     auto query_of = [&](const int64_t i, double (&q)[D]) {
         if (MODE == 1) {
@@ -775,7 +764,7 @@ __global__ void lg_iota_kernel(int64_t n, uint32_t* __restrict__ v) {
 // trimmed.cpp:57-62: the first new_n matches of the sorted order are kept
 __global__ void lg_select_kernel(const LargeDev* dev, int respect_done, int64_t n, int64_t new_n,
                                  const uint32_t* __restrict__ order, uint8_t* __restrict__ sel) {
-    if (lg_skip(dev, respect_done)) return;
+    if (lg_skip(lg_head(dev), respect_done)) return;
     int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r < n) sel[order[r]] = r < new_n ? 1 : 0;
 }
@@ -934,7 +923,7 @@ ICPX_DEV double key_to_f64(unsigned long long k) {
 // matching step that follows
 __global__ void fa_apply_kernel(LargeDev* dev, int respect_done, const double* __restrict__ src,
                                 double* __restrict__ cur, int64_t n) {
-    if (lg_skip(dev, respect_done)) return;
+    if (lg_skip(lg_head(dev), respect_done)) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i == 0) dev->dmax_key = 0;
     if (i >= n) return;
@@ -1041,7 +1030,7 @@ __global__ void __launch_bounds__(256)
 fa_maxdist_kernel(LargeDev* dev, int respect_done, const double* __restrict__ cur, int64_t n,
                   const double* __restrict__ dst, int64_t m, int split_len) {
     __shared__ unsigned long long smax[4];
-    if (lg_skip(dev, respect_done)) return;
+    if (lg_skip(lg_head(dev), respect_done)) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
     const int64_t t1 = t0 + split_len < m ? t0 + split_len : m;
@@ -1073,7 +1062,7 @@ __global__ void __launch_bounds__(256)
 fa_match_kernel(const LargeDev* dev, int respect_done, const double* __restrict__ cur, int64_t n,
                 const double* __restrict__ dst, int64_t m, int split_len, const double* __restrict__ nfd,
                 double feature_weight, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
-    if (lg_skip(dev, respect_done)) return;
+    if (lg_skip(lg_head(dev), respect_done)) return;
     int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
