@@ -22,3 +22,16 @@ def test_fuzz_fused_kernels_against_oracle(seed, prune, chunk):
                          capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "0 mismatches" in out.stdout
+
+
+
+def test_grid_filter_random_shapes():
+    """tests/tools/grid_filter_stress.py, twelve random cases: the 3D grid converge through f32 filter records and the
+    lean sorted-domain kernel against the f64 records (ICPX_GRID_FILTER=0) and against unseeded queries
+    (ICPX_GRID_SEED=0) — uniform, clustered, planar, duplicated, anisotropic and lattice clouds, far from the origin and
+    at tiny scale, sources sticking out of the targets' box: iteration counts, transforms, every neighbour and distance
+    bit-identical."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "grid_filter_stress.py"), "12", "11"],
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "all identical" in out.stdout
