@@ -22,7 +22,15 @@ struct LdsView {
     float* tf[3];    // f32 copy of the target SoA (candidate filter), null when not reserved
     int j0;          // cloud index of LDS slot 0
     const double* cloud = nullptr;  // KD searches: the whole target cloud (AoS, global), to tell coincident targets from ties
+    // Interleaved tiles (tiled search of the multi-kernel path): the tile holds every cstride/32-th chunk of 32 consecutive
+    // targets, so slot j stands for target j0 + (j / 32) * cstride + j % 32 (ascending in j).  0: the tile is contiguous.
+    int cstride = 0;
 };
+// cloud index of LDS slot j
+template <int D>
+ICPX_DEV int lds_cloud_index(const LdsView<D>& L, const int j) {
+    return L.cstride ? L.j0 + (j >> 5) * L.cstride + (j & 31) : L.j0 + j;
+}
 
 // brute-force NN of QPT register-resident queries against the LDS target cloud.
 // d2 = ((dx*dx) + dy*dy) + dz*dz with dx = target - query (trimmed.cpp:101), strict <,
@@ -139,6 +147,54 @@ ICPX_DEV void chunk_boxes(const LdsView<D>& L, const int m, double* __restrict__
         for (int d = 0; d < D; d++) {
             cb[(c * 2 + 0) * D + d] = lo[d];
             cb[(c * 2 + 1) * D + d] = hi[d];
+        }
+    }
+    __syncthreads();
+}
+
+// chunk_boxes with eight lanes per chunk (four targets each, then a butterfly over the eight): the tiled search computes
+// the boxes of its tile in every launch, and one thread walking 32 targets is a chain of a hundred LDS round trips.
+// blockDim.x must be a multiple of 64.  Same boxes.  Workgroup-wide; ends with a barrier.
+template <int D>
+ICPX_DEV void chunk_boxes_wide(const LdsView<D>& L, const int m, double* __restrict__ cb) {
+    const int nch = (m + kChunk - 1) / kChunk;
+    const int sub = threadIdx.x & 7;
+    for (int c0 = 0; c0 < nch; c0 += static_cast<int>(blockDim.x >> 3)) {
+        const int c = c0 + static_cast<int>(threadIdx.x >> 3);
+        double lo[D], hi[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            lo[d] = __builtin_inf();
+            hi[d] = -__builtin_inf();
+        }
+        if (c < nch) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = c * kChunk + sub * 4 + u;
+                if (j < m) {
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
+                        const double v = L.t[d][j];
+                        lo[d] = __builtin_fmin(lo[d], v);
+                        hi[d] = __builtin_fmax(hi[d], v);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o <= 4; o <<= 1) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                lo[d] = __builtin_fmin(lo[d], __shfl_xor(lo[d], o));
+                hi[d] = __builtin_fmax(hi[d], __shfl_xor(hi[d], o));
+            }
+        }
+        if (c < nch && sub == 0) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                cb[(c * 2 + 0) * D + d] = lo[d];
+                cb[(c * 2 + 1) * D + d] = hi[d];
+            }
         }
     }
     __syncthreads();
@@ -318,7 +374,7 @@ ICPX_DEV void exact_block(const double (&q)[D], const LdsView<D>& L, int blk, do
             df = c[d] - q[d];
             acc = acc + df * df;
         }
-        const int j = L.j0 + jb + u;
+        const int j = lds_cloud_index<D>(L, jb + u);
         if (TIES) *tie |= kd_tie_check<D>(act, acc, j, c, L.cloud, best, bidx) ? 1 : 0;
         bool better = act && (acc < best || (acc == best && j < bidx));
         best = better ? acc : best;
@@ -409,8 +465,10 @@ ICPX_DEV FilterFrame stage_targets(const double* __restrict__ dst, const int m, 
     for (int j = tid; j < m4; j += T) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            // perm: LDS slot j holds target perm[j] of the cloud (icpx_prune.h)
-            double v = j < m ? dst[static_cast<int64_t>(perm ? static_cast<int>(perm[j]) : j) * D + d] : __builtin_inf();
+            // perm: LDS slot j holds target perm[j] of the cloud (icpx_prune.h); interleaved tiles (L.cstride): slot j
+            // holds target (j / 32) * cstride + j % 32 counted from dst
+            const int src = perm ? static_cast<int>(perm[j]) : (L.cstride ? (j >> 5) * L.cstride + (j & 31) : j);
+            double v = j < m ? dst[static_cast<int64_t>(src) * D + d] : __builtin_inf();
             L.t[d][j] = v;
             if (filter && j < m) {
                 t_bad = t_bad || !(__builtin_fabs(v) < 1e300);
@@ -504,9 +562,18 @@ ICPX_DEV void seed_bound(const double (&q)[QPT][D], const LdsView<D>& L, int m, 
 // threshold.  One pending block per query slot is kept in a register; a second candidate for the
 // same slot flushes the first (wave-wide).  Waves with unusable coordinates take nn_lds.
 // TIES: tie[k] |= another non-coincident target within kKdNearUlps of slot k's minimum (icpx_kd.h)
-template <int D, int QPT, bool TIES = false>
+// CHUNKED (tiled search of the multi-kernel path): cb holds the bounding boxes of every kChunk consecutive slots
+// (chunk_boxes_wide); a chunk's eight blocks go through the filter only if SOME lane's query can have a target there
+// within (1 + 2^-40) of its running minimum — lb, the squared distance to the box computed like a d2 (monotone
+// roundings: no target of the chunk has a smaller computed d2, see nn_lds_chunked), compared strictly.  A skipped chunk
+// holds nothing that could improve a minimum or tie with it (a tie partner lies within kKdNearUlps), so the results
+// and the tie flags are those of the full scan.  Pays when queries and targets come in a coherent order (mesh
+// vertices, scans) AND the tiles are interleaved (LdsView::cstride): with contiguous tiles 70 % of queen.ply's chunks
+// are skipped and the launch is as long as before — as long as the few workgroups whose tile lies in their queries'
+// slab; interleaved, every workgroup holds its share of every slab.
+template <int D, int QPT, bool TIES = false, bool CHUNKED = false>
 ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4, const FilterFrame& F,
-                          double (&best)[QPT], int (&bidx)[QPT], int* tie = nullptr) {
+                          double (&best)[QPT], int (&bidx)[QPT], int* tie = nullptr, const double* __restrict__ cb = nullptr) {
     float q2[QPT][D], qn[QPT], e_dist, e_val;
     const bool ok = filter_queries<D, QPT>(q, F, q2, qn, e_dist, e_val);
     if (__any(!ok)) {
@@ -516,7 +583,7 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4
         nn_lds<D, QPT, TIES>(q, L, m4, lb, li, TIES ? lt : nullptr);
 #pragma unroll
         for (int k = 0; k < QPT; k++) {
-            const int j = L.j0 + li[k];
+            const int j = lds_cloud_index<D>(L, li[k]);
             const bool take = lb[k] < best[k] || (lb[k] == best[k] && j < bidx[k]);
             // (coincident targets are not told apart here: a flag too many only costs the resolution's time)
             if (TIES) tie[k] |= lt[k] | ((j != bidx[k] && lb[k] < __builtin_inf() && kd_near(lb[k], best[k])) ? 1 : 0);
@@ -534,7 +601,26 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4
         pend[k] = -1;
     }
     constexpr int G = QPT >= 2 ? 2 : 1;  // slots per branch: wider basic blocks schedule better
-    for (int jb = 0; jb < m4; jb += 4) {
+    constexpr int kOuter = CHUNKED ? kChunk : 4;
+    for (int jc = 0; jc < m4; jc += kOuter) {
+        if (CHUNKED) {
+            const int c = jc / kChunk;
+            bool need = false;
+#pragma unroll
+            for (int k = 0; k < QPT; k++) {
+                double lb = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const double lo = cb[(c * 2 + 0) * D + d], hi = cb[(c * 2 + 1) * D + d];
+                    const double g = __builtin_fmax(__builtin_fmax(lo - q[k][d], q[k][d] - hi), 0.0);
+                    lb = d == 0 ? g * g : lb + g * g;
+                }
+                need = need || !(lb > best[k] * 1.0000000000009095);  // (1 + 2^-40); NaN never skips
+            }
+            if (!__any(need)) continue;
+        }
+        const int jend = CHUNKED ? (jc + kChunk < m4 ? jc + kChunk : m4) : jc + 4;
+      for (int jb = jc; jb < jend; jb += 4) {
         f32x4 tc[D], tn;
         load_filter_block<D>(L, jb, tc, tn);
 #pragma unroll
@@ -561,6 +647,7 @@ ICPX_DEV void nn_filtered(const double (&q)[QPT][D], const LdsView<D>& L, int m4
                 }
             }
         }
+      }
     }
 #pragma unroll
     for (int k = 0; k < QPT; k++)
@@ -640,7 +727,7 @@ ICPX_DEV void nn_twomin(const double (&q)[QPT][D], const LdsView<D>& L, int m4, 
     if (__any(!ok)) {
         nn_lds<D, QPT, TIES>(q, L, m4, best, bidx, tie);
 #pragma unroll
-        for (int k = 0; k < QPT; k++) bidx[k] += L.j0;
+        for (int k = 0; k < QPT; k++) bidx[k] = lds_cloud_index<D>(L, bidx[k]);
         return;
     }
     float b1[QPT], b2[QPT];

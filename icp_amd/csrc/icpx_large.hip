@@ -181,6 +181,7 @@ struct LargeIcp {
     // tiled brute-force correspondence (mid-size clouds): (query tiles) x (target splits)
     bool tile = false;
     int splits = 0, split_len = 0;
+    bool tile_interleaved = false;  // split s holds the chunks s, s + splits, ... of 32 targets (lg_tile_nn_kernel)
     DevBuf part_d2, part_idx;
     // FeatureAware (feature_aware.cpp): radii, features (row r of point i at [r * count + i]) and the
     // normalised feature-distance matrix, stored target-major ([j * n + i]) for coalesced reads
@@ -577,8 +578,10 @@ constexpr int kTileMinSplit = 512;
 constexpr int64_t kFeatureMaxWork = int64_t(1) << 28;  // FeatureAware: n*m doubles of feature distances (2 GiB)
 constexpr int64_t kTileMaxWork = int64_t(1) << 30;  // n*m up to which ICPX_NN_AUTO prefers the tiled search
 
+// (f64 SoA + reduction scratch + f32 filter copy + the chunks' bounding boxes, icpx_filter.h)
 inline size_t tile_lds_bytes(int dim, int scap) {
-    return sizeof(double) * (static_cast<size_t>(dim) * scap + kTileScratch) + sizeof(float) * static_cast<size_t>(dim) * scap;
+    return sizeof(double) * (static_cast<size_t>(dim) * scap + kTileScratch) + sizeof(float) * static_cast<size_t>(dim) * scap +
+           sizeof(double) * 2 * static_cast<size_t>(dim) * ((scap + kChunk - 1) / kChunk + 1);
 }
 
 __global__ void lg_apply_guess_kernel(const double* __restrict__ guess, const double* __restrict__ src,
@@ -602,7 +605,13 @@ template <int D, int MODE, int QPT>
 __global__ void __launch_bounds__(kTileThreads)
 lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                   int64_t n, const double* __restrict__ dst, int64_t m, int split_len, int scap,
-                  const int64_t* __restrict__ nb_idx, double* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
+                  const int64_t* __restrict__ nb_idx, double* __restrict__ part_d2, int32_t* __restrict__ part_idx,
+                  const int interleaved = 0) {
+    // interleaved: split s of S holds the chunks s, s + S, s + 2 S ... of 32 consecutive targets (LdsView::cstride), and
+    // the search skips the chunks no query of the wave can need (nn_filtered<..., CHUNKED>).  Clouds in a coherent
+    // order — mesh vertices, scans — leave every workgroup its share of the needed chunks (with contiguous splits the
+    // launch is as long as the few workgroups whose split lies in their queries' neighbourhood).  Same results;
+    // ICPX_TILE_CHUNK=0: contiguous splits, every block scanned.
     extern __shared__ __attribute__((aligned(16))) double tile_lds[];
     const LgHead head = lg_head(dev);
     const int head_nn_valid = dev->nn_valid;
@@ -611,8 +620,16 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     for (int e = 0; e < (D + 1) * (D + 1); e++) head_xf.m[e] = MODE == 0 ? dev->step[e] : dev->st.transform[e];
     if (lg_skip(head, respect_done)) return;
     const int tid = threadIdx.x;
-    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
-    const int mt = static_cast<int>(m - t0 < split_len ? m - t0 : split_len);
+    int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
+    int mt = static_cast<int>(m - t0 < split_len ? m - t0 : split_len);
+    if (interleaved) {
+        const int S = static_cast<int>(gridDim.y), s = static_cast<int>(blockIdx.y);
+        const int nc = static_cast<int>((m + kChunk - 1) / kChunk);  // chunks of the cloud
+        const int mine = s < nc ? (nc - s + S - 1) / S : 0;            // chunks s, s + S, ...
+        const int tail = static_cast<int>(m - static_cast<int64_t>(nc - 1) * kChunk);  // targets of the cloud's last chunk
+        t0 = static_cast<int64_t>(s) * kChunk;
+        mt = mine * kChunk - ((mine > 0 && (nc - 1 - s) % S == 0) ? kChunk - tail : 0);
+    }
     const int m4 = (mt + 3) & ~3;
     LdsView<D> L;
     double* p = tile_lds;
@@ -627,7 +644,9 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     L.sval = nullptr;
     float* f = reinterpret_cast<float*>(p);
     for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
+    double* cbox = reinterpret_cast<double*>(f + static_cast<size_t>(D) * scap);  // (scap is a multiple of four: 8-byte aligned)
     L.j0 = static_cast<int>(t0);
+    L.cstride = interleaved ? static_cast<int>(gridDim.y) * kChunk : 0;
     L.cloud = dst;
     constexpr bool TIES = MODE != 2;  // the kd-tree methods (MODE 2 is trimmed ICP2: brute-force rule); icpx_kd.h
     // queries and seed indices first: their loads are in flight while the split is staged
@@ -680,7 +699,35 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     int tie[QPT];
 #pragma unroll
     for (int k = 0; k < QPT; k++) tie[k] = 0;
-    if (seeded) nn_filtered<D, QPT, TIES>(q, L, m4, F, best, bidx, tie);
+    // (clouds with non-finite or huge targets keep the plain scans and their conventions for such values)
+    const bool chunk_ok = interleaved != 0 && F.t_absmax < 1e18 && mt > 0;
+    if (chunk_ok) chunk_boxes_wide<D>(L, mt, cbox);
+    if (chunk_ok && !seeded) {
+        // no seed (the first search of a begin): every lane takes the chunk whose box is nearest to its query and
+        // evaluates it exactly — a bound from the query's neighbourhood — then searches like a seeded query
+        const int nch = (mt + kChunk - 1) / kChunk;
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            double lbmin = __builtin_inf();
+            int cmin = 0;
+            for (int c = 0; c < nch; c++) {
+                double lb = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const double lo = cbox[(c * 2 + 0) * D + d], hi = cbox[(c * 2 + 1) * D + d];
+                    const double g = __builtin_fmax(__builtin_fmax(lo - q[k][d], q[k][d] - hi), 0.0);
+                    lb = d == 0 ? g * g : lb + g * g;
+                }
+                const bool lt = lb < lbmin;
+                lbmin = lt ? lb : lbmin;
+                cmin = lt ? c : cmin;
+            }
+            const int j1 = min((cmin + 1) * kChunk, m4);
+            for (int jb = cmin * kChunk; jb < j1; jb += 4) exact_block<D, TIES>(q[k], L, jb, best[k], bidx[k], TIES ? &tie[k] : nullptr);
+        }
+    }
+    if (chunk_ok) nn_filtered<D, QPT, TIES, true>(q, L, m4, F, best, bidx, tie, cbox);
+    else if (seeded) nn_filtered<D, QPT, TIES>(q, L, m4, F, best, bidx, tie);
     else nn_twomin<D, QPT, TIES>(q, L, m4, F, best, bidx, tie);
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
@@ -2293,7 +2340,7 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
     dim3 grid(static_cast<unsigned>((lg->n + tile_queries - 1) / tile_queries), static_cast<unsigned>(lg->splits));
     hipLaunchKernelGGL(kern, grid, dim3(kTileThreads), lds, lg->stream, dev, respect, lg->src.as<double>(),
                        lg->cur.as<double>(), lg->n, lg->dst.as<double>(), lg->m, lg->split_len, lg->split_len,
-                       lg->nb_idx.as<int64_t>(), lg->part_d2.as<double>(), lg->part_idx.as<int32_t>());
+                       lg->nb_idx.as<int64_t>(), lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->tile_interleaved ? 1 : 0);
     ICPX_HIP(hipGetLastError());
     hipLaunchKernelGGL((lg_tile_merge_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n,
                        lg->splits, lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->nb_idx.as<int64_t>(),
@@ -2521,6 +2568,14 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         if (len > kTileMaxSplit) len = kTileMaxSplit;
         splits = (m + len - 1) / len;
         if (splits > 65535) return fail(ICPX_ERR_UNSUPPORTED, "target cloud too large for the tiled search; use nn = grid");
+        // interleaved splits with chunk skipping (lg_tile_nn_kernel): a split's capacity is a whole number of chunks
+        lg->tile_interleaved = !lg->feature && knobs().tile_chunk != 0;
+        if (lg->tile_interleaved) {
+            const int64_t nc = (m + kChunk - 1) / kChunk;
+            if (splits > nc) splits = nc;
+            while (((nc + splits - 1) / splits) * kChunk > kTileMaxSplit) splits++;
+            len = ((nc + splits - 1) / splits) * kChunk;
+        }
         lg->splits = static_cast<int>(splits);
         lg->split_len = static_cast<int>(len);
         ICPX_TRY(lg->part_d2.reserve(sizeof(double) * static_cast<size_t>(splits) * n));

@@ -1231,3 +1231,43 @@ def test_polled_done_flag_equals_copied_flag_across_reuse(icp, queen, knob):
         assert np.array_equal(p1.transform, p2.transform) and np.array_equal(p1.transform, c1.transform), name
         assert np.array_equal(c1.transform, c2.transform) and np.array_equal(pm, cm), name
         assert p3.iteration_count == c3.iteration_count and np.array_equal(p3.transform, c3.transform), name
+
+
+def test_tiled_search_interleaved_chunks_are_bit_identical(icp, ob, queen, knob):
+    """The tiled search of the multi-kernel path hands split s every S-th chunk of 32 consecutive targets and skips
+    the chunks no query of a wave can need (ICPX_TILE_CHUNK=1, the default); ICPX_TILE_CHUNK=0 keeps contiguous splits
+    and scans every block.  Same converge bit for bit — queen.ply (coherent vertex order: most chunks skipped), a
+    lattice (exact ties everywhere), random order, and target counts around the chunk and split boundaries (1, 31, 32,
+    33 ... 9 999 targets); the oracle at the sizes it covers."""
+    rng = np.random.default_rng(77)
+    crit = dict(max_iterations=8, transform_tol=(1e-9, 1e-9))
+    cases = [("queen", queen[0], queen[1], "vanilla", False)]
+    lat = np.stack(np.meshgrid(np.arange(20.0), np.arange(20.0), np.arange(20.0), indexing="ij"), -1).reshape(-1, 3)
+    cases.append(("lattice", lat[rng.permutation(len(lat))][:5000] + 0.5, lat, "vanilla", True))
+    for m in (1, 31, 32, 33, 95, 500, 1025, 3071, 3073, 9999):
+        t = rng.uniform(-5, 5, (m, 3))
+        s = rng.uniform(-5, 5, (5000, 3))
+        cases.append((f"m{m}", s, t, "trimmed" if m % 2 else "vanilla", m <= 3073))
+    srt = rng.uniform(-5, 5, (12000, 3))
+    srt = srt[np.argsort(srt[:, 2])]                      # slabs along z, like a mesh
+    cases.append(("sorted", srt[::2] + rng.normal(0, 0.02, (6000, 3)), srt, "vanilla", False))
+    for name, s, t, method, oracle in cases:
+        out = []
+        for env in ("1", "0"):
+            knob.set("ICPX_TILE_CHUNK", env)
+            cfg = icp.Config()
+            cfg.set("nn", "brute")
+            cfg.set("max_distance", 0.8)
+            d = driver(icp, icp.ICP3, method, crit, cfg)
+            r = d.converge(s, t)
+            nb = d.icp_.debug_neighbors()
+            out.append((r.iteration_count, r.transform.copy(), np.array(nb[0]), np.array(nb[1])))
+        knob.reset("ICPX_TILE_CHUNK")
+        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]), name
+        assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3]), name
+        if oracle:
+            o = dev_oracle(ob, 3, method, max_distance=0.8)
+            ro = o.converge(s, t, None, ob.make_criteria(**crit))
+            assert out[0][0] == ro.iteration_count and np.array_equal(out[0][1], ro.transform), name
+            for u, v in zip(out[0][2:], o.neighbors()):
+                assert np.array_equal(u, v), name
