@@ -700,8 +700,9 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
 #pragma unroll
     for (int k = 0; k < QPT; k++) tie[k] = 0;
     // (clouds with non-finite or huge targets keep the plain scans and their conventions for such values)
-    const bool chunk_ok = interleaved != 0 && F.t_absmax < 1e18 && mt > 0;
-    if (chunk_ok) chunk_boxes_wide<D>(L, mt, cbox);
+    // ... and so do clouds whose chunks are not compact (random order: the boxes exclude nothing)
+    bool chunk_ok = interleaved != 0 && F.t_absmax < 1e18 && mt > 0;
+    if (chunk_ok) chunk_ok = chunk_boxes_wide<D>(L, mt, cbox);
     if (chunk_ok && !seeded) {
         // no seed (the first search of a begin): every lane takes the chunk whose box is nearest to its query and
         // evaluates it exactly — a bound from the query's neighbourhood — then searches like a seeded query
