@@ -182,6 +182,7 @@ struct LargeIcp {
     bool tile = false;
     int splits = 0, split_len = 0;
     bool tile_interleaved = false;  // split s holds the chunks s, s + splits, ... of 32 targets (lg_tile_nn_kernel)
+    DevBuf tile_prep;               // per split: filter frame, chunk boxes, compactness (lg_tile_prep_kernel), once per begin()
     DevBuf part_d2, part_idx;
     // FeatureAware (feature_aware.cpp): radii, features (row r of point i at [r * count + i]) and the
     // normalised feature-distance matrix, stored target-major ([j * n + i]) for coalesced reads
@@ -599,6 +600,75 @@ __global__ void lg_apply_guess_kernel(const double* __restrict__ guess, const do
     cur[i * 3 + 2] = q[2];
 }
 
+// A workgroup's target split and its LDS layout (f64 SoA, scratch, f32 filter copy, chunk boxes).
+// interleaved: split s of S holds the chunks s, s + S, s + 2 S ... of 32 consecutive targets (LdsView::cstride).
+template <int D>
+struct TileView {
+    LdsView<D> L;
+    double* cbox;
+    int64_t t0;
+    int mt, m4;
+};
+template <int D>
+ICPX_DEV TileView<D> tile_view(double* tile_lds, const double* __restrict__ dst, const int64_t m, const int split_len,
+                               const int scap, const int interleaved) {
+    TileView<D> V;
+    V.t0 = static_cast<int64_t>(blockIdx.y) * split_len;
+    V.mt = static_cast<int>(m - V.t0 < split_len ? m - V.t0 : split_len);
+    if (interleaved) {
+        const int S = static_cast<int>(gridDim.y), s = static_cast<int>(blockIdx.y);
+        const int nc = static_cast<int>((m + kChunk - 1) / kChunk);  // chunks of the cloud
+        const int mine = s < nc ? (nc - s + S - 1) / S : 0;            // chunks s, s + S, ...
+        const int tail = static_cast<int>(m - static_cast<int64_t>(nc - 1) * kChunk);  // targets of the cloud's last chunk
+        V.t0 = static_cast<int64_t>(s) * kChunk;
+        V.mt = mine * kChunk - ((mine > 0 && (nc - 1 - s) % S == 0) ? kChunk - tail : 0);
+    }
+    V.m4 = (V.mt + 3) & ~3;
+    LdsView<D>& L = V.L;
+    double* p = tile_lds;
+    for (int d = 0; d < 3; d++) {
+        L.t[d] = d < D ? p : nullptr;
+        if (d < D) p += scap;
+    }
+    L.gs = p;
+    p += kTileScratch;
+    L.bc = nullptr;
+    L.skey = nullptr;
+    L.sval = nullptr;
+    float* f = reinterpret_cast<float*>(p);
+    for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
+    V.cbox = reinterpret_cast<double*>(f + static_cast<size_t>(D) * scap);  // (scap is a multiple of four: 8-byte aligned)
+    L.j0 = static_cast<int>(V.t0);
+    L.cstride = interleaved ? static_cast<int>(gridDim.y) * kChunk : 0;
+    L.cloud = dst;
+    return V;
+}
+
+// What a split's workgroups would compute in every launch of lg_tile_nn_kernel, once per begin() (the targets do not
+// change): the filter frame (stage_targets), the chunk boxes and whether they are compact (chunk_boxes_wide).
+// prep + split * kTilePrepStride: [0..2] frame centre, [3] max |t - centre|, [4] compact, [8...] the boxes.
+// grid = (1, splits); the dynamic LDS of lg_tile_nn_kernel.
+constexpr int kTilePrepStride = 8 + 2 * 3 * (kTileMaxSplit / kChunk + 2);
+template <int D>
+__global__ void __launch_bounds__(kTileThreads)
+lg_tile_prep_kernel(const double* __restrict__ dst, int64_t m, int split_len, int scap, int interleaved, double* __restrict__ prep) {
+    extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+    TileView<D> V = tile_view<D>(tile_lds, dst, m, split_len, scap, interleaved);
+    const FilterFrame F = stage_targets<D>(dst + V.t0 * D, V.mt, V.m4, kTileThreads, V.L, true);
+    bool compact = interleaved != 0 && F.t_absmax < 1e18 && V.mt > 0;
+    if (compact) compact = chunk_boxes_wide<D>(V.L, V.mt, V.cbox);
+    double* out = prep + static_cast<size_t>(blockIdx.y) * kTilePrepStride;
+    if (threadIdx.x == 0) {
+        for (int d = 0; d < 3; d++) out[d] = F.c0[d];
+        out[3] = F.t_absmax;
+        out[4] = compact ? 1.0 : 0.0;
+    }
+    if (compact) {
+        const int nw = 2 * D * ((V.mt + kChunk - 1) / kChunk);
+        for (int i = threadIdx.x; i < nw; i += kTileThreads) out[8 + i] = V.cbox[i];
+    }
+}
+
 // MODE as in lg_nn_kernel (0: queries = step * running cloud, computed here; 1: untransformed source;
 // 2: transform * source)
 template <int D, int MODE, int QPT>
@@ -606,7 +676,8 @@ __global__ void __launch_bounds__(kTileThreads)
 lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restrict__ src, const double* __restrict__ cur,
                   int64_t n, const double* __restrict__ dst, int64_t m, int split_len, int scap,
                   const int64_t* __restrict__ nb_idx, double* __restrict__ part_d2, int32_t* __restrict__ part_idx,
-                  const int interleaved = 0) {
+                  const int interleaved, const double* __restrict__ prep) {
+    // prep (lg_tile_prep_kernel): the split's filter frame and chunk boxes, computed once per begin()
     // interleaved: split s of S holds the chunks s, s + S, s + 2 S ... of 32 consecutive targets (LdsView::cstride), and
     // the search skips the chunks no query of the wave can need (nn_filtered<..., CHUNKED>).  Clouds in a coherent
     // order — mesh vertices, scans — leave every workgroup its share of the needed chunks (with contiguous splits the
@@ -620,34 +691,11 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     for (int e = 0; e < (D + 1) * (D + 1); e++) head_xf.m[e] = MODE == 0 ? dev->step[e] : dev->st.transform[e];
     if (lg_skip(head, respect_done)) return;
     const int tid = threadIdx.x;
-    int64_t t0 = static_cast<int64_t>(blockIdx.y) * split_len;
-    int mt = static_cast<int>(m - t0 < split_len ? m - t0 : split_len);
-    if (interleaved) {
-        const int S = static_cast<int>(gridDim.y), s = static_cast<int>(blockIdx.y);
-        const int nc = static_cast<int>((m + kChunk - 1) / kChunk);  // chunks of the cloud
-        const int mine = s < nc ? (nc - s + S - 1) / S : 0;            // chunks s, s + S, ...
-        const int tail = static_cast<int>(m - static_cast<int64_t>(nc - 1) * kChunk);  // targets of the cloud's last chunk
-        t0 = static_cast<int64_t>(s) * kChunk;
-        mt = mine * kChunk - ((mine > 0 && (nc - 1 - s) % S == 0) ? kChunk - tail : 0);
-    }
-    const int m4 = (mt + 3) & ~3;
-    LdsView<D> L;
-    double* p = tile_lds;
-    for (int d = 0; d < 3; d++) {
-        L.t[d] = d < D ? p : nullptr;
-        if (d < D) p += scap;
-    }
-    L.gs = p;
-    p += kTileScratch;
-    L.bc = nullptr;
-    L.skey = nullptr;
-    L.sval = nullptr;
-    float* f = reinterpret_cast<float*>(p);
-    for (int d = 0; d < 3; d++) L.tf[d] = d < D ? f + static_cast<size_t>(d) * scap : nullptr;
-    double* cbox = reinterpret_cast<double*>(f + static_cast<size_t>(D) * scap);  // (scap is a multiple of four: 8-byte aligned)
-    L.j0 = static_cast<int>(t0);
-    L.cstride = interleaved ? static_cast<int>(gridDim.y) * kChunk : 0;
-    L.cloud = dst;
+    TileView<D> V = tile_view<D>(tile_lds, dst, m, split_len, scap, interleaved);
+    LdsView<D>& L = V.L;
+    double* const cbox = V.cbox;
+    const int64_t t0 = V.t0;
+    const int mt = V.mt, m4 = V.m4;
     constexpr bool TIES = MODE != 2;  // the kd-tree methods (MODE 2 is trimmed ICP2: brute-force rule); icpx_kd.h
     // queries and seed indices first: their loads are in flight while the split is staged
     double q[QPT][D], best[QPT];
@@ -677,7 +725,31 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
         int64_t j = (seeded && valid) ? nb_idx[i] : 0;
         seed[k] = j < 0 ? 0 : (j >= m ? m - 1 : j);
     }
-    const FilterFrame F = stage_targets<D>(dst + t0 * D, mt, m4, kTileThreads, L, true);
+    // frame and boxes from the begin-time pass: the split is staged in ONE pass (f64 SoA and its f32 copy about the
+    // frame's centre, exactly stage_targets' values) behind one barrier — no bounding-box and |t - c| reductions
+    FilterFrame F;
+    const double* pr = prep + static_cast<size_t>(blockIdx.y) * kTilePrepStride;
+#pragma unroll
+    for (int d = 0; d < 3; d++) F.c0[d] = pr[d];
+    F.t_absmax = pr[3];
+    const bool compact = pr[4] != 0.0;
+    {
+        const double* tb = dst + t0 * D;
+        for (int j = tid; j < m4; j += kTileThreads) {
+            const int srcj = L.cstride ? (j >> 5) * L.cstride + (j & 31) : j;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const double v = j < mt ? tb[static_cast<int64_t>(srcj) * D + d] : __builtin_inf();
+                L.t[d][j] = v;
+                L.tf[d][j] = j < mt ? static_cast<float>(v - F.c0[d]) : 1e18f;
+            }
+        }
+        if (compact) {
+            const int nw = 2 * D * ((mt + kChunk - 1) / kChunk);
+            for (int i = tid; i < nw; i += kTileThreads) cbox[i] = pr[8 + i];
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < QPT; k++) {
         best[k] = __builtin_inf();
@@ -701,8 +773,7 @@ lg_tile_nn_kernel(const LargeDev* dev, int respect_done, const double* __restric
     for (int k = 0; k < QPT; k++) tie[k] = 0;
     // (clouds with non-finite or huge targets keep the plain scans and their conventions for such values)
     // ... and so do clouds whose chunks are not compact (random order: the boxes exclude nothing)
-    bool chunk_ok = interleaved != 0 && F.t_absmax < 1e18 && mt > 0;
-    if (chunk_ok) chunk_ok = chunk_boxes_wide<D>(L, mt, cbox);
+    const bool chunk_ok = compact;  // (interleaved, usable frame, non-empty split, compact chunks: lg_tile_prep_kernel)
     if (chunk_ok && !seeded) {
         // no seed (the first search of a begin): every lane takes the chunk whose box is nearest to its query and
         // evaluates it exactly — a bound from the query's neighbourhood — then searches like a seeded query
@@ -2111,7 +2182,7 @@ void large_destroy(LargeIcp* lg) {
     if (lg->kd_ev_tree) (void)hipEventDestroy(lg->kd_ev_tree);
     for (DevBuf* b : {&lg->src, &lg->dst, &lg->cur, &lg->guess, &lg->nb_idx, &lg->nb_cost, &lg->sel, &lg->part,
                       &lg->cntp, &lg->dev, &lg->nb_pt, &lg->cur_s, &lg->idx_s, &lg->pt_s, &lg->sort_keys, &lg->sort_iota, &lg->sort_order, &lg->sort_tmp,
-                      &lg->part_d2, &lg->part_idx, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree, &lg->kd_scratch})
+                      &lg->part_d2, &lg->part_idx, &lg->tile_prep, &lg->f_rad, &lg->f_feat_a, &lg->f_feat_b, &lg->f_nfd, &lg->kd_list, &lg->kd_tree, &lg->kd_scratch})
         b->release();
     grid_destroy(lg->grid);
     bvh_destroy(lg->bvh);
@@ -2341,7 +2412,8 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
     dim3 grid(static_cast<unsigned>((lg->n + tile_queries - 1) / tile_queries), static_cast<unsigned>(lg->splits));
     hipLaunchKernelGGL(kern, grid, dim3(kTileThreads), lds, lg->stream, dev, respect, lg->src.as<double>(),
                        lg->cur.as<double>(), lg->n, lg->dst.as<double>(), lg->m, lg->split_len, lg->split_len,
-                       lg->nb_idx.as<int64_t>(), lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->tile_interleaved ? 1 : 0);
+                       lg->nb_idx.as<int64_t>(), lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->tile_interleaved ? 1 : 0,
+                       lg->tile_prep.as<double>());
     ICPX_HIP(hipGetLastError());
     hipLaunchKernelGGL((lg_tile_merge_kernel<D, METHOD, MODE>), dim3(nb), dim3(256), 0, lg->stream, dev, respect, lg->n,
                        lg->splits, lg->part_d2.as<double>(), lg->part_idx.as<int32_t>(), lg->nb_idx.as<int64_t>(),
@@ -2579,6 +2651,17 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
         }
         lg->splits = static_cast<int>(splits);
         lg->split_len = static_cast<int>(len);
+        if (!lg->feature) {
+            // the splits' filter frames and chunk boxes, once per begin (the targets are on the stream's way already)
+            ICPX_TRY(lg->tile_prep.reserve(sizeof(double) * kTilePrepStride * static_cast<size_t>(splits)));
+            auto pk = D == 2 ? lg_tile_prep_kernel<2> : lg_tile_prep_kernel<3>;
+            ICPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(tile_lds_bytes(3, kTileMaxSplit))));
+            hipLaunchKernelGGL(pk, dim3(1, static_cast<unsigned>(splits)), dim3(kTileThreads), tile_lds_bytes(D, static_cast<int>(len)),
+                               lg->stream, lg->dst.as<double>(), m, static_cast<int>(len), static_cast<int>(len),
+                               lg->tile_interleaved ? 1 : 0, lg->tile_prep.as<double>());
+            ICPX_HIP(hipGetLastError());
+        }
         ICPX_TRY(lg->part_d2.reserve(sizeof(double) * static_cast<size_t>(splits) * n));
         ICPX_TRY(lg->part_idx.reserve(sizeof(int32_t) * static_cast<size_t>(splits) * n));
     } else {
