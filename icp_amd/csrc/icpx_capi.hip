@@ -70,6 +70,7 @@ bool set_knob(Knobs& k, const char* name, const char* value) {
     else if (n == "ICPX_GRID_DENSITY") k.grid_density = (value && iv >= 1 && iv <= 1000) ? iv : 0;
     else if (n == "ICPX_GRID_SD") k.grid_sd = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_GRID_FILTER") k.grid_filter = value ? (value[0] != '0') : 1;
+    else if (n == "ICPX_KD_EAGER") k.kd_eager = value ? (value[0] == '1' ? 1 : (value[0] == '0' ? 0 : -1)) : -1;
     else if (n == "ICPX_TILE_CHUNK") k.tile_chunk = value ? (value[0] != '0') : 1;
     else if (n == "ICPX_TILE_MIN") k.tile_min = (value && iv >= 64 && iv <= 3072) ? (iv & ~3) : 0;
     else if (n == "ICPX_TILE_WGS") k.tile_wgs = (value && iv >= 64 && iv <= 65536) ? iv : 0;
@@ -95,7 +96,7 @@ Knobs& knobs() {
     static Knobs k;
     static const bool from_env = [] {
         for (const char* n : {"ICPX_PRUNE", "ICPX_FILTER", "ICPX_SCHED", "ICPX_SCHED_STEPS", "ICPX_PRUNE_HANDLES",
-                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_GRID_FILTER", "ICPX_TILE_CHUNK", "ICPX_DEFER_SPARSE", "ICPX_CHUNK_SKIP", "ICPX_ZERO_COPY", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
+                              "ICPX_NO_GROUP_SUMS", "ICPX_COOP", "ICPX_GRID_COOP", "ICPX_GRID_SEED", "ICPX_GRID_SD", "ICPX_GRID_FILTER", "ICPX_TILE_CHUNK", "ICPX_KD_EAGER", "ICPX_DEFER_SPARSE", "ICPX_CHUNK_SKIP", "ICPX_ZERO_COPY", "ICPX_GRID_DENSITY", "ICPX_TILE_WGS", "ICPX_TILE_MIN", "ICPX_POLL_DONE", "ICPX_FUSE_PREPASS", "ICPX_FUSED_SINGLE_MAX", "ICPX_GEOM"})
             if (const char* v = std::getenv(n)) set_knob(k, n, v);
         return true;
     }();

@@ -48,6 +48,7 @@ struct Knobs {
     std::atomic<int> chunk_skip{1};      // ICPX_CHUNK_SKIP: 0 = trimmed ICP2's brute-force kernels search with the f32 filter
     std::atomic<int> defer_sparse{1};    // ICPX_DEFER_SPARSE: 0 = pruned kernels keep the pairs whose grid is a poor index
     std::atomic<int> grid_sd{1};         // ICPX_GRID_SD: 0 = no sorted-domain copy of the running cloud for the 3D grid search (LargeIcp::sd)
+    std::atomic<int> kd_eager{-1};       // ICPX_KD_EAGER: -1 auto (the tree of a small target is built at begin() only for handles that met tie partners before), 0 never, 1 always for small targets
     std::atomic<int> tile_chunk{1};      // ICPX_TILE_CHUNK: 0 = the tiled search of the multi-kernel path keeps contiguous splits and scans every block
     std::atomic<int> grid_filter{1};     // ICPX_GRID_FILTER: 0 = seeded HBM grid queries of the 3D methods scan the 32-byte f64 records (no f32 filter records)
     std::atomic<int> grid_seed{1};       // ICPX_GRID_SEED: 0 = HBM grid queries of a converge never start from the previous step's neighbour

@@ -198,6 +198,7 @@ struct LargeIcp {
     hipStream_t kd_stream = nullptr;
     hipEvent_t kd_ev_cloud = nullptr, kd_ev_tree = nullptr;
     bool kd_wait = false;    // the main stream has not yet waited for kd_ev_tree
+    bool kd_tied = false;    // a converge on this handle stalled at flagged queries before (large_begin: build the tree eagerly)
     int* h_done = nullptr;  // pinned: [0] done flag, [1] iterations finished, [2] stalled at a tie (written by the device, large_converge polls)
     int* h_done_dev = nullptr;   // the same memory as the device sees it
     int* poll_dev = nullptr;     // h_done_dev while large_converge runs, else null: kernels then publish nothing
@@ -2526,6 +2527,7 @@ int lg_kd_service(LargeIcp* lg, int mode, bool* stalled) {
                                lg->dst.as<double>(), lg->m, sd ? lg->idx_s.as<int64_t>() : lg->nb_idx.as<int64_t>(), 1024, lg->stream,
                                lg->nb_pt.as<double>(), sd ? lg->grid->q_perm.as<uint32_t>() : nullptr, sd ? lg->pt_s.as<double>() : nullptr));
     *stalled = true;
+    lg->kd_tied = true;
     return ICPX_OK;
 }
 int lg_iteration_mode(const LargeIcp* lg) { return lg->dim == 3 ? 0 : 3; }
@@ -2577,7 +2579,13 @@ int large_begin(LargeIcp* lg, const double* source, int64_t n, const double* tar
     lg->kd_ready = false;
     lg->kd_wait = false;
     if (lg->kd_rule) ICPX_TRY(lg->kd_list.reserve(sizeof(uint32_t) * n));
-    if (lg->kd_rule && m <= kKdEagerMax) {
+    // The tree of a small target at begin(), on a stream of its own — only for a handle that met tie partners before
+    // (kd_tied: lg_kd_service): clouds of measured coordinates hardly ever hold two targets within 4 ulps of a query's
+    // minimum, and then neither the build nor the resolve launch behind every search is needed (queen.ply: 1.13 ->
+    // 0.93 ms).  A handle's first cloud with ties pays one stall (lg_kd_service) and builds eagerly from then on.
+    // ICPX_KD_EAGER (development): 0 never, 1 always.
+    const int eager = knobs().kd_eager.load();
+    if (lg->kd_rule && m <= kKdEagerMax && (eager == 1 || (eager < 0 && lg->kd_tied))) {
         if (!lg->kd_stream) {
             ICPX_HIP(hipStreamCreateWithFlags(&lg->kd_stream, hipStreamNonBlocking));
             ICPX_HIP(hipEventCreateWithFlags(&lg->kd_ev_cloud, hipEventDisableTiming));

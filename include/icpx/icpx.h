@@ -254,7 +254,7 @@ int icpx_converge_batch_noalloc(int dim, int method, const icpx_params* params, 
 
 /* Development knobs (no reference counterpart).  The ICPX_* environment variables (ICPX_PRUNE,
  * ICPX_FILTER, ICPX_SCHED, ICPX_SCHED_STEPS, ICPX_PRUNE_HANDLES, ICPX_NO_GROUP_SUMS, ICPX_COOP,
- * ICPX_GRID_COOP, ICPX_GRID_SEED, ICPX_GRID_SD, ICPX_GRID_FILTER, ICPX_TILE_CHUNK, ICPX_DEFER_SPARSE, ICPX_CHUNK_SKIP, ICPX_ZERO_COPY, ICPX_GRID_DENSITY, ICPX_TILE_WGS, ICPX_TILE_MIN, ICPX_POLL_DONE, ICPX_FUSE_PREPASS,
+ * ICPX_GRID_COOP, ICPX_GRID_SEED, ICPX_GRID_SD, ICPX_GRID_FILTER, ICPX_TILE_CHUNK, ICPX_KD_EAGER, ICPX_DEFER_SPARSE, ICPX_CHUNK_SKIP, ICPX_ZERO_COPY, ICPX_GRID_DENSITY, ICPX_TILE_WGS, ICPX_TILE_MIN, ICPX_POLL_DONE, ICPX_FUSE_PREPASS,
  * ICPX_FUSED_SINGLE_MAX, ICPX_GEOM) are read once, when the library is first used; this call changes one afterwards
  * (value NULL = built-in default); an unknown name is ICPX_ERR_INVALID.  Every setting computes the same
  * results; they select between kernels.  Not thread-safe against running calls. */

@@ -1271,3 +1271,43 @@ def test_tiled_search_interleaved_chunks_are_bit_identical(icp, ob, queen, knob)
             assert out[0][0] == ro.iteration_count and np.array_equal(out[0][1], ro.transform), name
             for u, v in zip(out[0][2:], o.neighbors()):
                 assert np.array_equal(u, v), name
+
+
+def test_kd_tree_eager_or_on_demand_is_the_same_converge(icp, ob, queen, knob):
+    """kd-tree tie rule on the multi-kernel path: the target's tree is built at begin() (ICPX_KD_EAGER=1), or only when
+    a search meets tie partners — the device stalls, the host builds the tree, the flagged queries are resolved, the
+    step resumes (ICPX_KD_EAGER=0) — or, the default, on demand until a handle has stalled once and at begin() from
+    then on.  Same converge bit for bit, neighbours included: a lattice (ties in every step) through the tiled search
+    and through the grid, queen.ply (no ties: no tree at all by default); the oracle on the lattice."""
+    rng = np.random.default_rng(78)
+    crit = dict(max_iterations=8, transform_tol=(1e-9, 1e-9))
+    lat = np.stack(np.meshgrid(np.arange(20.0), np.arange(20.0), np.arange(20.0), indexing="ij"), -1).reshape(-1, 3)
+    lsrc = lat[rng.permutation(len(lat))][:5000] + 0.5
+    for name, s, t, nn, oracle in (("lattice-tiled", lsrc, lat, "brute", True), ("lattice-grid", lsrc, lat, "grid", False),
+                                   ("queen", queen[0], queen[1], "brute", False)):
+        cfg = icp.Config()
+        cfg.set("nn", nn)
+        cfg.set("max_distance", 0.8)
+
+        def run(d):
+            r = d.converge(s, t)
+            nb = d.icp_.debug_neighbors()
+            return r.iteration_count, r.transform.copy(), np.array(nb[0]), np.array(nb[1])
+
+        out = {}
+        for env in ("1", "0"):
+            knob.set("ICPX_KD_EAGER", env)
+            out[env] = run(driver(icp, icp.ICP3, "vanilla", crit, cfg))
+        knob.reset("ICPX_KD_EAGER")
+        d = driver(icp, icp.ICP3, "vanilla", crit, cfg)
+        out["first"] = run(d)    # on demand
+        out["second"] = run(d)   # the lattice: at begin() now; queen: on demand again
+        for k in ("0", "first", "second"):
+            assert out[k][0] == out["1"][0] and np.array_equal(out[k][1], out["1"][1]), (name, k)
+            assert np.array_equal(out[k][2], out["1"][2]) and np.array_equal(out[k][3], out["1"][3]), (name, k)
+        if oracle:
+            o = dev_oracle(ob, 3, "vanilla", max_distance=0.8)
+            ro = o.converge(s, t, None, ob.make_criteria(**crit))
+            assert out["1"][0] == ro.iteration_count and np.array_equal(out["1"][1], ro.transform), name
+            for u, v in zip(out["1"][2:], o.neighbors()):
+                assert np.array_equal(u, v), name
