@@ -1311,3 +1311,34 @@ def test_kd_tree_eager_or_on_demand_is_the_same_converge(icp, ob, queen, knob):
             assert out["1"][0] == ro.iteration_count and np.array_equal(out["1"][1], ro.transform), name
             for u, v in zip(out["1"][2:], o.neighbors()):
                 assert np.array_equal(u, v), name
+
+
+def test_first_tiled_search_seeds_from_a_sample(icp, ob):
+    """The first tiled search of a begin() starts every query from the nearest of a strided sample of the targets
+    (lg_tile_seed_kernel).  The neighbours after one iteration are those of the brute-force rule all the same — on a
+    random cloud, far from the origin, and with non-finite values among the queries and the targets (the sampled
+    positions included), where the search falls back to its unseeded form."""
+    rng = np.random.default_rng(79)
+    cfg = icp.Config()
+    cfg.set("nn", "brute")
+    cases = []
+    q, t = rng.uniform(-5, 5, (5000, 3)), rng.uniform(-5, 5, (6001, 3))
+    cases.append(("random", q, t))
+    cases.append(("offset", q + 3.0e6, t + 3.0e6))
+    tb = t.copy()
+    tb[0] = np.nan                      # the sample's origin
+    tb[12] = [np.inf, 0.0, 0.0]         # a sampled position (stride 12)
+    tb[100:140, 1] = np.nan
+    cases.append(("bad-targets", q, tb))
+    qb = q.copy()
+    qb[7] = np.nan
+    qb[4000, 2] = np.inf
+    cases.append(("bad-queries", qb, t))
+    for name, a, b in cases:
+        x = icp.ICP3.from_method("vanilla", cfg)
+        x.begin(a, b, np.eye(4))
+        x.iterate()
+        got = np.array(x.debug_neighbors()[0])
+        oi, _ = ob.nn_brute(a, b)
+        ok = np.isfinite(a).all(axis=1)
+        assert np.array_equal(got[ok], oi[ok]), (name, np.nonzero(got != oi)[0][:8])
