@@ -825,7 +825,7 @@ template <int D, int MODE>
 __global__ void __launch_bounds__(256)
 lg_tile_seed_kernel(LargeDev* dev, int respect_done, int64_t n, const double* __restrict__ src, const double* __restrict__ cur,
                     const double* __restrict__ dst, int64_t m, int stride, int64_t* __restrict__ nb_idx) {
-    __shared__ float st[D][kTileSeedSamples];
+    __shared__ __attribute__((aligned(16))) float st[D][kTileSeedSamples];
     const LgHead head = lg_head(dev);
     Xf<D> xf;
 #pragma unroll
@@ -833,20 +833,25 @@ lg_tile_seed_kernel(LargeDev* dev, int respect_done, int64_t n, const double* __
     if (lg_skip(head, respect_done)) return;
     const int tid = threadIdx.x;
     const int ns = static_cast<int>((m + stride - 1) / stride);  // (<= kTileSeedSamples: the host's stride)
+    const int ns4 = (ns + 3) & ~3;
     double o[D];  // f32 about the first target: clouds far from the origin keep their resolution
 #pragma unroll
     for (int d = 0; d < D; d++) o[d] = dst[d];
-    for (int k = tid; k < ns; k += 256)
+    for (int k = tid; k < ns4; k += 256)
 #pragma unroll
-        for (int d = 0; d < D; d++) st[d][k] = static_cast<float>(dst[static_cast<int64_t>(k) * stride * D + d] - o[d]);
+        for (int d = 0; d < D; d++)
+            st[d][k] = k < ns ? static_cast<float>(dst[static_cast<int64_t>(k) * stride * D + d] - o[d]) : __builtin_inff();
     __syncthreads();
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + tid;
-    if (i == 0) dev->nn_valid = 2;
-    if (i >= n) return;
+    // four lanes per query, each with every fourth group of four samples (a wave reads 64 contiguous bytes per row)
+    const int part = tid & 3;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + (tid >> 2);
+    if (blockIdx.x == 0 && tid == 0) dev->nn_valid = 2;
+    const bool valid = i < n;
+    const int64_t ic = valid ? i : 0;
     // the query of lg_tile_nn_kernel
     double pnt[D], q[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) pnt[d] = MODE == 0 ? cur[i * D + d] : src[i * D + d];
+    for (int d = 0; d < D; d++) pnt[d] = MODE == 0 ? cur[ic * D + d] : src[ic * D + d];
     if (MODE == 2 || MODE == 3 || MODE == 0) {
         const XfRows<D> xr = xf_rows<D>(xf);
         xf_apply<D>(xr, pnt, q);
@@ -859,19 +864,36 @@ lg_tile_seed_kernel(LargeDev* dev, int respect_done, int64_t n, const double* __
     for (int d = 0; d < D; d++) qf[d] = static_cast<float>(q[d] - o[d]);
     float best = __builtin_inff();
     int bs = 0;
-    for (int k = 0; k < ns; k++) {
-        float acc = 0.0f;
+    for (int g = part * 4; g < ns4; g += 16) {
+        float4 c[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            const float df = st[d][k] - qf[d];
-            acc = fmaf(df, df, acc);
+        for (int d = 0; d < D; d++) c[d] = *reinterpret_cast<const float4*>(&st[d][g]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const float t = u == 0 ? c[d].x : (u == 1 ? c[d].y : (u == 2 ? c[d].z : c[d].w));
+                const float df = t - qf[d];
+                acc = fmaf(df, df, acc);
+            }
+            const bool take = acc < best;  // (NaN and inf never)
+            best = take ? acc : best;
+            bs = take ? g + u : bs;
         }
-        const bool take = acc < best;  // (NaN and inf never)
-        best = take ? acc : best;
-        bs = take ? k : bs;
     }
-    if (!(best < __builtin_inff())) dev->seed_bad = 1;
-    nb_idx[i] = static_cast<int64_t>(bs) * stride;
+#pragma unroll
+    for (int w = 1; w <= 2; w <<= 1) {
+        const float ob = __shfl_xor(best, w);
+        const int os = __shfl_xor(bs, w);
+        const bool take = ob < best || (ob == best && os < bs);
+        best = take ? ob : best;
+        bs = take ? os : bs;
+    }
+    if (valid && part == 0) {
+        if (!(best < __builtin_inff())) dev->seed_bad = 1;
+        nb_idx[i] = static_cast<int64_t>(bs) * stride;
+    }
 }
 
 // (d2, index) minimum over the splits, then the epilogue of lg_nn_kernel
@@ -2459,7 +2481,7 @@ int enqueue_nn_search(LargeIcp* lg, int respect) {
     if (lg->tile_first && lg->splits >= 4) {
         // the first search of a begin: seeds from a sample of the targets, so that every split starts from one bound
         const int stride = static_cast<int>((lg->m + kTileSeedSamples - 1) / kTileSeedSamples);
-        hipLaunchKernelGGL((lg_tile_seed_kernel<D, MODE>), dim3(static_cast<unsigned>((lg->n + 255) / 256)), dim3(256), 0, lg->stream,
+        hipLaunchKernelGGL((lg_tile_seed_kernel<D, MODE>), dim3(static_cast<unsigned>((lg->n + 63) / 64)), dim3(256), 0, lg->stream,
                            dev, respect, lg->n, lg->src.as<double>(), lg->cur.as<double>(), lg->dst.as<double>(), lg->m, stride,
                            lg->nb_idx.as<int64_t>());
         ICPX_HIP(hipGetLastError());
